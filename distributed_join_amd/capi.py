@@ -1,0 +1,136 @@
+"""ctypes binding of the C ABI in include/dj_engine.h (libdj_engine.so, HIP for gfx950).
+
+There is no CPU implementation behind these symbols: if the shared library is missing
+the import fails loudly, and every compute entry point needs a GPU.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdj_engine.so")
+
+# ---- constants of include/dj_engine.h ---------------------------------------------
+DJ_OK = 0
+DJ_E_INVALID, DJ_E_HIP, DJ_E_NOMEM, DJ_E_CLOCK_RANGE, DJ_E_TOO_LARGE = -1, -2, -3, -4, -5
+DJ_NIL = 0xFFFFFFFF
+DJ_NOT_QUEUED = 0xFFFFFFFFFFFFFFFF
+DJ_JOIN_WAITING, DJ_JOIN_COMPLETE, DJ_JOIN_NOT_FOUND = 1, 2, 3
+DJ_JOIN_BAD_POSITION, DJ_JOIN_NEAREST_NOT_QUEUED, DJ_JOIN_TOO_LONG = 4, 5, 6
+DJ_FORK_CREATED, DJ_FORK_TABLE_FULL, DJ_FORK_NO_SPACE, DJ_FORK_BAD_COUNT = 1, 2, 3, 4
+DJ_ACK_DONE, DJ_ACK_REQUEUED_DIRTY, DJ_ACK_RETRY = 1, 2, 3
+DJ_ACK_DROPPED_EXHAUSTED, DJ_ACK_DONE_NO_METADATA = 4, 5
+DJ_CONT_TIMEOUT, DJ_CONT_NO_METADATA = 1, 2
+CONT_VOID = 0x80000000
+
+# ---- record layouts (little-endian, no padding surprises: all fields naturally aligned)
+FORK_REC = np.dtype([("fp_lo", "<u8"), ("fp_hi", "<u8"), ("count", "<u4"), ("reserved", "<u4"),
+                     ("deadline_ms", "<u8")])
+JOIN_REC = np.dtype([("fp_lo", "<u8"), ("fp_hi", "<u8"), ("position", "<u4"), ("len", "<u4"),
+                     ("max_wait_s", "<u4"), ("reserved", "<u4")])
+CONT = np.dtype([("fp_lo", "<u8"), ("fp_hi", "<u8"), ("deadline_ms", "<u8"), ("publish_at", "<u8"),
+                 ("count", "<u4"), ("flags", "<u4"), ("retry_publish", "<u4"), ("retry_timeout", "<u4"),
+                 ("pos_base", "<u8"), ("reserved", "<u8")])
+SWEEP_RESULT = np.dtype([("n_conts", "<u4"), ("more", "<u4"), ("n_positions", "<u8")])
+STATS = np.dtype([("slots", "<u8"), ("live", "<u8"), ("tombstones", "<u8"), ("arena_units_used", "<u8"),
+                  ("arena_units_free", "<u8")])
+assert FORK_REC.itemsize == 32 and JOIN_REC.itemsize == 32 and CONT.itemsize == 64
+assert SWEEP_RESULT.itemsize == 16 and STATS.itemsize == 40
+
+
+class Config(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("device", ctypes.c_int32),
+                ("capacity_barriers", ctypes.c_uint64), ("arena_bytes", ctypes.c_uint64),
+                ("max_count", ctypes.c_uint32), ("payload_stride", ctypes.c_uint32),
+                ("max_batch", ctypes.c_uint32), ("max_retry_publish", ctypes.c_uint32),
+                ("max_retry_timeout_publish", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
+                ("check_publish_delay_ms", ctypes.c_uint64)]
+
+
+# every symbol include/dj_engine.h declares
+SYMBOLS = ["dj_create", "dj_destroy", "dj_last_error", "dj_sync", "dj_stream", "dj_fingerprint",
+           "dj_fingerprint_batch", "dj_fork_batch", "dj_join_batch", "dj_pop_due", "dj_sweep",
+           "dj_ack_batch", "dj_recover", "dj_snapshot_one", "dj_store_in_publish_queue",
+           "dj_queue_scores", "dj_get_stats", "dj_owner_of", "dj_partition_joins"]
+
+_lib = None
+
+
+def load():
+    """Load libdj_engine.so and declare the prototypes.  Raises if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u32, u64, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
+    L.dj_create.restype = i32
+    L.dj_create.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(vp)]
+    L.dj_destroy.restype = None
+    L.dj_destroy.argtypes = [vp]
+    L.dj_last_error.restype = ctypes.c_char_p
+    L.dj_last_error.argtypes = [vp]
+    L.dj_sync.restype = i32
+    L.dj_sync.argtypes = [vp]
+    L.dj_stream.restype = vp
+    L.dj_stream.argtypes = [vp]
+    L.dj_fingerprint.restype = None
+    L.dj_fingerprint.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    L.dj_fingerprint_batch.restype = None
+    L.dj_fingerprint_batch.argtypes = [vp, vp, ctypes.c_size_t, vp]
+    L.dj_fork_batch.restype = i32
+    L.dj_fork_batch.argtypes = [vp, u32, vp, vp]
+    L.dj_join_batch.restype = i32
+    L.dj_join_batch.argtypes = [vp, u32, vp, vp, u64, u64, vp]
+    L.dj_pop_due.restype = i32
+    L.dj_pop_due.argtypes = [vp, u64, u32, vp, vp, vp]
+    L.dj_sweep.restype = i32
+    L.dj_sweep.argtypes = [vp, u64, u32, u64, vp, vp, vp, vp, vp, vp]
+    L.dj_ack_batch.restype = i32
+    L.dj_ack_batch.argtypes = [vp, u32, vp, vp, vp, u64, vp]
+    L.dj_recover.restype = i32
+    L.dj_recover.argtypes = [vp, u64, u32, vp, vp, vp, vp]
+    L.dj_snapshot_one.restype = i32
+    L.dj_snapshot_one.argtypes = [vp, u64, u64, i32, vp, vp, vp, vp]
+    L.dj_store_in_publish_queue.restype = i32
+    L.dj_store_in_publish_queue.argtypes = [vp, u64, u64, u64]
+    L.dj_queue_scores.restype = i32
+    L.dj_queue_scores.argtypes = [vp, u64, u64, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    L.dj_get_stats.restype = i32
+    L.dj_get_stats.argtypes = [vp, vp]
+    L.dj_owner_of.restype = u32
+    L.dj_owner_of.argtypes = [u64, u64, u32]
+    L.dj_partition_joins.restype = i32
+    L.dj_partition_joins.argtypes = [vp, u32, u32, vp, vp, u64, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def fingerprint(barrier_id):
+    """128-bit fingerprint of one barrier-id (str or bytes) -> (fp_lo, fp_hi)."""
+    b = barrier_id.encode() if isinstance(barrier_id, str) else bytes(barrier_id)
+    lo, hi = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    buf = ctypes.create_string_buffer(b, len(b) + 1)
+    load().dj_fingerprint(ctypes.cast(buf, ctypes.c_void_p), len(b), ctypes.byref(lo), ctypes.byref(hi))
+    return lo.value, hi.value
+
+
+def fingerprint_many(ids):
+    """Fingerprints of a sequence of ids -> uint64 array of shape (n, 2) = (fp_lo, fp_hi)."""
+    bs = [i.encode() if isinstance(i, str) else bytes(i) for i in ids]
+    blob = np.frombuffer(b"".join(bs) or b"\0", dtype=np.uint8).copy()
+    offs = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        np.cumsum([len(b) for b in bs], out=offs[1:])
+    out = np.zeros((len(bs), 2), dtype=np.uint64)
+    load().dj_fingerprint_batch(blob.ctypes.data_as(ctypes.c_void_p), offs.ctypes.data_as(ctypes.c_void_p),
+                                len(bs), out.ctypes.data_as(ctypes.c_void_p))
+    return out
+
+
+def owner_of(fp_lo, fp_hi, n_ranks):
+    return int(load().dj_owner_of(int(fp_lo), int(fp_hi), int(n_ranks)))

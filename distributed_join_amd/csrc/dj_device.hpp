@@ -1,0 +1,268 @@
+// dj_device.hpp — device-side data layout and helpers of the barrier engine (gfx950).
+//
+// HBM layout (one engine = one GPU):
+//   slots[]      64-byte records, open addressing with linear probing, power-of-two size.
+//                One record = one Redis key family of the reference:
+//                "<id>:metadata", "<id>:join-ts", "<id>:join-ts-read" and the presence set of
+//                the hash "<id>" (reference redis.clj:42-73).
+//   q_primary[]  score of the slot's barrier in "publish-queue"        (redis.clj:36), or NQ
+//   q_backup[]   score in "publish-queue-backup"                       (redis.clj:37), or NQ
+//                Two flat u64 arrays so the sweeps stream 8 bytes per slot.
+//   arena        payload slabs in 64-byte units, one slab per barrier, size class = count
+//                rounded up to a power of two:
+//                  [bitmap words, only when class > 64 positions]
+//                  [posmeta: class * {u32 len, u32 max_wait}]           (64-byte aligned)
+//                  [payload: class * payload_stride bytes]              (64-byte aligned)
+//   free rings   per size class, slabs returned by deleted barriers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "dj_engine.h"
+
+namespace dj {
+
+constexpr uint64_t FP_EMPTY = 0;       // never-used slot (fp_lo)
+constexpr uint64_t FP_TOMB = 1;        // deleted slot (fp_lo), fp_hi = 0
+constexpr uint64_t NQ = DJ_NOT_QUEUED;
+constexpr uint32_t META_HAS = 1u;      // metadata key exists
+constexpr uint32_t RETRY_NIL = 0xFFu;  // retry counter absent
+constexpr int NUM_CLASSES = 11;        // 1, 2, 4 ... 1024 positions
+constexpr uint64_t NODST = ~0ull;
+constexpr uint32_t CONT_VOID = 0x80000000u;  // internal: descriptor index allocated but not popped
+
+struct __attribute__((aligned(64))) Slot {
+    uint64_t fp_lo, fp_hi;
+    uint32_t count;         // :count of the metadata, 0 without metadata
+    uint32_t meta;          // bit0 META_HAS | publish-retry-cnt << 8 | timeout-publish-retry-cnt << 16
+    uint32_t slab;          // arena offset in 64-byte units, 0 = none
+    uint32_t chain;         // transient per-batch link head (event index + 1); 0 between batches
+    uint64_t deadline;      // :timeout-secs
+    uint64_t join_ts;       // "<id>:join-ts", 0 = nil
+    uint64_t join_ts_read;  // "<id>:join-ts-read", 0 = nil
+    uint64_t bits;          // count <= 64: presence bitmap; count > 64: number of present positions
+};
+static_assert(sizeof(Slot) == 64, "slot must be one 64-byte line");
+
+__host__ __device__ inline uint32_t meta_pack(bool has, uint32_t rp, uint32_t rt) {
+    return (has ? META_HAS : 0u) | ((rp & 0xFFu) << 8) | ((rt & 0xFFu) << 16);
+}
+__host__ __device__ inline uint32_t meta_retry_pub(uint32_t m) { return (m >> 8) & 0xFFu; }
+__host__ __device__ inline uint32_t meta_retry_to(uint32_t m) { return (m >> 16) & 0xFFu; }
+__host__ __device__ inline uint32_t retry_to_api(uint32_t r) { return r == RETRY_NIL ? DJ_NIL : r; }
+__host__ __device__ inline uint32_t retry_from_api(uint32_t r) { return r == DJ_NIL ? RETRY_NIL : (r > 0xFEu ? 0xFEu : r); }
+
+// ---- slab geometry ---------------------------------------------------------------
+__host__ __device__ inline uint32_t class_of(uint32_t count) {
+    uint32_t k = 0;
+    while ((1u << k) < count) ++k;
+    return k;
+}
+__host__ __device__ inline uint32_t class_positions(uint32_t k) { return 1u << k; }
+__host__ __device__ inline uint32_t slab_bitmap_bytes(uint32_t k) {
+    uint32_t p = 1u << k;
+    return p > 64 ? ((p / 64 * 8 + 63) & ~63u) : 0;
+}
+__host__ __device__ inline uint32_t slab_posmeta_off(uint32_t k) { return slab_bitmap_bytes(k); }
+__host__ __device__ inline uint32_t slab_payload_off(uint32_t k) {
+    return slab_posmeta_off(k) + (((1u << k) * 8 + 63) & ~63u);
+}
+__host__ __device__ inline uint32_t slab_units(uint32_t k, uint32_t stride) {
+    return (slab_payload_off(k) + (1u << k) * stride) / 64;
+}
+
+struct Table {
+    Slot* slots;
+    uint64_t* q_primary;
+    uint64_t* q_backup;
+    uint64_t mask;               // slots - 1
+    uint8_t* arena;
+    uint64_t arena_units;
+    unsigned long long* bump;    // next never-used arena unit
+    uint32_t* ring[NUM_CLASSES]; // freed slabs per class
+    uint32_t ring_cap[NUM_CLASSES];
+    unsigned int* ring_head;     // [NUM_CLASSES] pop side
+    unsigned int* ring_tail;     // [NUM_CLASSES] push side
+    unsigned int* ring_tail_snap;// [NUM_CLASSES] tail at the start of the current call: pops stop here
+    unsigned long long* stat;    // [0] live slots, [1] tombstones, [2] free units in rings
+    uint32_t stride;
+    uint32_t max_count;
+    uint32_t max_retry_publish, max_retry_timeout_publish;
+    uint64_t check_publish_delay_ms;
+};
+
+// per-batch scratch, sized by max_batch
+struct Work {
+    uint64_t* node;      // join link: next(25) | position(10) << 25 | max_wait(29) << 35
+    uint64_t* dst;       // join: where the event's message goes, NODST = superseded / rejected
+    uint32_t* touched;   // slots touched by the current join batch (first toucher appends)
+    uint32_t* complex_;  // slots whose chain is too long for the register path
+    uint32_t* slot_of;   // fork: slot of record i
+    uint32_t* cont_slot; // sweep: slot of continuation k
+    unsigned int* counters;  // C_* below
+};
+enum { C_TOUCHED = 0, C_COMPLEX = 1, C_ERROR = 2, C_COUNT = 8 };
+
+// ---- atomics (agent scope, relaxed) ------------------------------------------------
+template <class T>
+__device__ inline T a_load(T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T>
+__device__ inline void a_store(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T>
+__device__ inline T a_add(T* p, T v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T>
+__device__ inline T a_max(T* p, T v) { return __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T>
+__device__ inline T a_xchg(T* p, T v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T>
+__device__ inline bool a_cas(T* p, T expect, T v) {
+    return __hip_atomic_compare_exchange_strong(p, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ inline uint32_t lane_id() { return __lane_id(); }
+
+// Append one element per lane with pred set; one atomic per wave.  Must be reached by the
+// wave in converged control flow.  Returns the index, or 0xFFFFFFFF for lanes without pred.
+__device__ inline uint32_t wave_append(unsigned int* counter, bool pred) {
+    uint64_t m = __ballot(pred);
+    if (m == 0) return 0xFFFFFFFFu;
+    uint32_t lane = lane_id();
+    int leader = __ffsll((unsigned long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = a_add(counter, (unsigned int)__popcll(m));
+    base = __shfl(base, leader);
+    return pred ? base + (uint32_t)__popcll(m & ((1ull << lane) - 1)) : 0xFFFFFFFFu;
+}
+
+// ---- probing -----------------------------------------------------------------------
+// Read-only lookup.  Valid in every kernel that does not insert (joins, sweeps, acks of
+// existing barriers): slot keys only change between launches there.
+__device__ inline int64_t find_slot(const Table& t, uint64_t lo, uint64_t hi) {
+    uint64_t s = lo & t.mask;
+    for (uint64_t p = 0; p <= t.mask; ++p, s = (s + 1) & t.mask) {
+        const ulonglong2 k = *reinterpret_cast<const ulonglong2*>(&t.slots[s]);
+        if (k.x == lo && k.y == hi) return (int64_t)s;
+        if (k.x == FP_EMPTY) return -1;
+    }
+    return -1;
+}
+
+// Lookup-or-insert for kernels that create slots (fork, retry write-back, orphan queue
+// entries).  Slots only go EMPTY/TOMB -> key inside such a kernel; a plain load that shows a
+// full key is therefore final, a plain load that shows EMPTY/TOMB is re-read atomically.
+// Returns the slot or -1 when the table is full; *created says whether this call claimed it.
+__device__ inline int64_t find_or_claim(const Table& t, uint64_t lo, uint64_t hi, bool* created) {
+    *created = false;
+    for (int attempt = 0; attempt < 64; ++attempt) {
+        uint64_t s = lo & t.mask;
+        int64_t tomb = -1;
+        bool restart = false;
+        for (uint64_t p = 0; p <= t.mask && !restart; ++p, s = (s + 1) & t.mask) {
+            Slot* sl = &t.slots[s];
+            uint64_t klo = sl->fp_lo;
+            if (klo == FP_EMPTY || klo == FP_TOMB) klo = a_load(&sl->fp_lo);
+            if (klo == lo) {
+                // same low half: wait (without spinning inside the iteration) for the claimer's
+                // high half, then compare
+                uint64_t khi = a_load(&sl->fp_hi);
+                for (int spin = 0; khi == 0 && spin < (1 << 20); ++spin) {
+                    __builtin_amdgcn_s_sleep(1);
+                    khi = a_load(&sl->fp_hi);
+                }
+                if (khi == hi) return (int64_t)s;
+                continue;  // another key with the same low half
+            }
+            if (klo == FP_TOMB) {
+                if (tomb < 0) tomb = (int64_t)s;
+                continue;
+            }
+            if (klo != FP_EMPTY) continue;  // another key
+            // end of the probe chain: the key is absent, claim the first tombstone or this slot
+            uint64_t target = tomb >= 0 ? (uint64_t)tomb : s;
+            uint64_t expect = tomb >= 0 ? FP_TOMB : FP_EMPTY;
+            Slot* tl = &t.slots[target];
+            if (a_cas(&tl->fp_lo, expect, lo)) {
+                a_store(&tl->fp_hi, hi);
+                *created = true;
+                a_add(&t.stat[0], 1ull);
+                if (tomb >= 0) a_add(&t.stat[1], ~0ull);
+                return (int64_t)target;
+            }
+            restart = true;  // somebody else claimed it: probe again from the home slot
+        }
+        if (!restart) return -1;
+    }
+    return -1;
+}
+
+// ---- slab allocation ---------------------------------------------------------------
+__device__ inline uint32_t slab_alloc(const Table& t, uint32_t k) {
+    // freed slabs first, bounded by the tail snapshot so a pop never reads an entry that a
+    // concurrent push has not written yet
+    // (head and tail are free-running 32-bit counters, ring_cap is a power of two)
+    unsigned int snap = t.ring_tail_snap[k];
+    if ((int)(snap - a_load(&t.ring_head[k])) > 0) {
+        unsigned int h = a_add(&t.ring_head[k], 1u);
+        if ((int)(snap - h) > 0) {
+            a_add(&t.stat[2], ~(unsigned long long)slab_units(k, t.stride) + 1ull);
+            return t.ring[k][h & (t.ring_cap[k] - 1)];
+        }
+        a_add(&t.ring_head[k], ~0u);
+    }
+    uint32_t units = slab_units(k, t.stride);
+    unsigned long long u = a_add(t.bump, (unsigned long long)units);
+    if (u + units > t.arena_units) {
+        a_add(t.bump, ~(unsigned long long)units + 1ull);
+        return 0;
+    }
+    return (uint32_t)u;
+}
+__device__ inline void slab_free(const Table& t, uint32_t k, uint32_t slab) {
+    if (slab == 0) return;
+    unsigned int tl = a_add(&t.ring_tail[k], 1u);
+    t.ring[k][tl & (t.ring_cap[k] - 1)] = slab;
+    a_add(&t.stat[2], (unsigned long long)slab_units(k, t.stride));
+}
+
+// redis/complete's deletions (redis.clj:180-185) for a slot this thread owns
+__device__ inline void delete_slot(const Table& t, uint64_t s) {
+    Slot* sl = &t.slots[s];
+    if (sl->slab) slab_free(t, class_of(sl->count), sl->slab);
+    sl->count = 0;
+    sl->meta = 0;
+    sl->slab = 0;
+    sl->chain = 0;
+    sl->deadline = 0;
+    sl->join_ts = 0;
+    sl->join_ts_read = 0;
+    sl->bits = 0;
+    sl->fp_hi = 0;
+    sl->fp_lo = FP_TOMB;
+    t.q_primary[s] = NQ;
+    t.q_backup[s] = NQ;
+    a_add(&t.stat[0], ~0ull);
+    a_add(&t.stat[1], 1ull);
+}
+
+__device__ inline uint64_t* slab_bitmap(const Table& t, uint32_t slab) {
+    return reinterpret_cast<uint64_t*>(t.arena + (uint64_t)slab * 64);
+}
+__device__ inline uint2* slab_posmeta(const Table& t, uint32_t slab, uint32_t k) {
+    return reinterpret_cast<uint2*>(t.arena + (uint64_t)slab * 64 + slab_posmeta_off(k));
+}
+__device__ inline uint8_t* slab_payload(const Table& t, uint32_t slab, uint32_t k) {
+    return t.arena + (uint64_t)slab * 64 + slab_payload_off(k);
+}
+
+// node packing of the join link pass
+__device__ inline uint64_t node_pack(uint32_t next, uint32_t pos, uint32_t mw) {
+    return (uint64_t)next | ((uint64_t)pos << 25) | ((uint64_t)mw << 35);
+}
+__device__ inline uint32_t node_next(uint64_t x) { return (uint32_t)(x & 0x1FFFFFFu); }
+__device__ inline uint32_t node_pos(uint64_t x) { return (uint32_t)((x >> 25) & 0x3FFu); }
+__device__ inline uint32_t node_mw(uint64_t x) { return (uint32_t)(x >> 35); }
+
+__device__ inline uint64_t dst_pack(uint32_t slab, uint32_t count) { return (uint64_t)slab | ((uint64_t)count << 32); }
+
+}  // namespace dj

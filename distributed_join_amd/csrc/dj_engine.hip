@@ -1,0 +1,459 @@
+// dj_engine.hip — host side of the C ABI declared in include/dj_engine.h.
+//
+// One engine owns one GPU, one HIP stream and all device memory of its barrier table.
+// Every entry point validates its arguments on the host (sizes, alignment, clock range)
+// before a kernel is launched, so that a kernel never sees a shape it was not written for.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "dj_kernels.hpp"
+
+using namespace dj;
+
+struct dj_engine {
+    dj_config cfg;
+    Table t;
+    Work w;
+    hipStream_t stream;
+    // single-key staging (device) for dj_snapshot_one / dj_queue_scores
+    dj_cont* d_one_cont;
+    uint64_t* d_one_scores;
+    uint32_t* d_one_lens;
+    uint32_t* d_one_mws;
+    uint8_t* d_one_payload;
+    int32_t* d_one_err;
+    dj_sweep_result* d_result;   // internal result block when the caller passes none
+    uint32_t* d_part_counts;     // partition scratch: blocks * ranks
+    void* allocs[64];
+    int n_allocs;
+    std::string err;
+};
+
+static std::string g_create_err;
+
+static int fail(dj_engine* e, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (e) e->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define HIP_TRY(e, call)                                                                            \
+    do {                                                                                            \
+        hipError_t _r = (call);                                                                     \
+        if (_r != hipSuccess) return fail(e, DJ_E_HIP, "%s failed: %s", #call, hipGetErrorString(_r)); \
+    } while (0)
+
+static int dev_alloc(dj_engine* e, void** p, size_t bytes) {
+    if (e->n_allocs >= 64) return fail(e, DJ_E_INVALID, "allocation table full");
+    hipError_t r = hipMalloc(p, bytes ? bytes : 16);
+    if (r != hipSuccess) return fail(e, DJ_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(r));
+    e->allocs[e->n_allocs++] = *p;
+    return DJ_OK;
+}
+#define ALLOC(e, ptr, bytes)                                         \
+    do {                                                             \
+        int _rc = dev_alloc(e, (void**)&(ptr), (bytes));             \
+        if (_rc != DJ_OK) return _rc;                                \
+    } while (0)
+
+static bool clock_ok(uint64_t now_ms) { return now_ms >= 1000000000000ull && now_ms < 9000000000000ull; }
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static uint32_t grid_for(uint64_t n, uint32_t block) { return (uint32_t)((n + block - 1) / block); }
+static uint64_t next_pow2(uint64_t v) { uint64_t p = 1; while (p < v) p <<= 1; return p; }
+
+// ---- fingerprint ------------------------------------------------------------------
+static inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static inline uint64_t fmix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+
+extern "C" void dj_fingerprint(const void* id, size_t len, uint64_t* fp_lo, uint64_t* fp_hi) {
+    const uint8_t* p = static_cast<const uint8_t*>(id);
+    uint64_t h1 = 0x9E3779B97F4A7C15ull ^ (uint64_t)len;
+    uint64_t h2 = 0xC2B2AE3D27D4EB4Full + ((uint64_t)len << 32);
+    size_t i = 0;
+    for (; i + 8 <= len; i += 8) {
+        uint64_t w;
+        memcpy(&w, p + i, 8);
+        h1 = rotl64(h1 ^ w, 27) * 0x9FB21C651E98DF25ull + 0x52DCE729ull;
+        h2 = rotl64(h2 + w, 31) * 0xD6E8FEB86659FD93ull ^ (h1 >> 29);
+    }
+    uint64_t w = 0;
+    memcpy(&w, p + i, len - i);
+    w ^= (uint64_t)(len - i) << 56;
+    h1 = rotl64(h1 ^ w, 27) * 0x9FB21C651E98DF25ull + 0x52DCE729ull;
+    h2 = rotl64(h2 + w, 31) * 0xD6E8FEB86659FD93ull ^ (h1 >> 29);
+    uint64_t lo = fmix64(h1 ^ rotl64(h2, 23));
+    uint64_t hi = fmix64(h2 + 0x9E3779B97F4A7C15ull * (h1 | 1));
+    if (lo < 2) lo += 2;   // 0 and 1 mark empty and deleted slots
+    if (hi == 0) hi = 1;   // 0 marks a slot whose key is still being written
+    *fp_lo = lo;
+    *fp_hi = hi;
+}
+
+extern "C" void dj_fingerprint_batch(const uint8_t* bytes, const uint64_t* offsets, size_t n, uint64_t* out) {
+    for (size_t i = 0; i < n; ++i) dj_fingerprint(bytes + offsets[i], offsets[i + 1] - offsets[i], &out[2 * i], &out[2 * i + 1]);
+}
+
+extern "C" uint32_t dj_owner_of(uint64_t fp_lo, uint64_t fp_hi, uint32_t n_ranks) {
+    return n_ranks ? owner_of(fp_lo, fp_hi, n_ranks) : 0;
+}
+
+// ---- lifecycle -----------------------------------------------------------------------
+extern "C" const char* dj_last_error(const dj_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+
+extern "C" void dj_destroy(dj_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    if (e->stream) {
+        (void)hipStreamSynchronize(e->stream);
+        (void)hipStreamDestroy(e->stream);
+    }
+    for (int i = 0; i < e->n_allocs; ++i) (void)hipFree(e->allocs[i]);
+    delete e;
+}
+
+static int create_impl(dj_engine* e) {
+    const dj_config& c = e->cfg;
+    HIP_TRY(e, hipSetDevice(c.device));
+    HIP_TRY(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    Table& t = e->t;
+    memset(&t, 0, sizeof t);
+    uint64_t slots = next_pow2(c.capacity_barriers * 2);
+    if (slots < 1024) slots = 1024;
+    if (slots > (1ull << 30)) return fail(e, DJ_E_INVALID, "capacity_barriers too large (max 2^29)");
+    t.mask = slots - 1;
+    t.stride = c.payload_stride;
+    t.max_count = c.max_count;
+    t.max_retry_publish = c.max_retry_publish;
+    t.max_retry_timeout_publish = c.max_retry_timeout_publish;
+    t.check_publish_delay_ms = c.check_publish_delay_ms;
+    t.arena_units = c.arena_bytes / 64;
+    if (t.arena_units >= (1ull << 32)) return fail(e, DJ_E_INVALID, "arena_bytes too large (max 256 GiB)");
+    ALLOC(e, t.slots, slots * sizeof(Slot));
+    ALLOC(e, t.q_primary, slots * 8);
+    ALLOC(e, t.q_backup, slots * 8);
+    ALLOC(e, t.arena, t.arena_units * 64);
+    ALLOC(e, t.bump, 8);
+    ALLOC(e, t.ring_head, NUM_CLASSES * 4);
+    ALLOC(e, t.ring_tail, NUM_CLASSES * 4);
+    ALLOC(e, t.ring_tail_snap, NUM_CLASSES * 4);
+    ALLOC(e, t.stat, 4 * 8);
+    const uint32_t max_class = class_of(c.max_count);
+    for (uint32_t k = 0; k < NUM_CLASSES; ++k) {
+        // live + freed slabs of a class can never exceed arena / slab size
+        uint64_t cap = k <= max_class ? t.arena_units / slab_units(k, t.stride) + 1 : 1;
+        if (cap > c.capacity_barriers * 2 + 1) cap = c.capacity_barriers * 2 + 1;
+        cap = next_pow2(cap);
+        t.ring_cap[k] = (uint32_t)cap;
+        ALLOC(e, t.ring[k], cap * 4);
+    }
+    HIP_TRY(e, hipMemsetAsync(t.slots, 0, slots * sizeof(Slot), e->stream));
+    HIP_TRY(e, hipMemsetAsync(t.q_primary, 0xFF, slots * 8, e->stream));
+    HIP_TRY(e, hipMemsetAsync(t.q_backup, 0xFF, slots * 8, e->stream));
+    const unsigned long long one = 1;   // arena unit 0 is reserved: slab 0 means "no slab"
+    HIP_TRY(e, hipMemcpyAsync(t.bump, &one, 8, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemsetAsync(t.ring_head, 0, NUM_CLASSES * 4, e->stream));
+    HIP_TRY(e, hipMemsetAsync(t.ring_tail, 0, NUM_CLASSES * 4, e->stream));
+    HIP_TRY(e, hipMemsetAsync(t.ring_tail_snap, 0, NUM_CLASSES * 4, e->stream));
+    HIP_TRY(e, hipMemsetAsync(t.stat, 0, 4 * 8, e->stream));
+
+    Work& w = e->w;
+    const uint64_t nb = c.max_batch;
+    ALLOC(e, w.node, nb * 8);
+    ALLOC(e, w.dst, nb * 8);
+    ALLOC(e, w.touched, nb * 4);
+    ALLOC(e, w.complex_, nb * 4);
+    ALLOC(e, w.slot_of, nb * 4);
+    ALLOC(e, w.cont_slot, (nb > slots ? nb : slots) * 4);
+    ALLOC(e, w.counters, C_COUNT * 4);
+    HIP_TRY(e, hipMemsetAsync(w.counters, 0, C_COUNT * 4, e->stream));
+
+    ALLOC(e, e->d_one_cont, sizeof(dj_cont));
+    ALLOC(e, e->d_one_scores, 16);
+    ALLOC(e, e->d_one_lens, (size_t)c.max_count * 4);
+    ALLOC(e, e->d_one_mws, (size_t)c.max_count * 4);
+    ALLOC(e, e->d_one_payload, (size_t)c.max_count * c.payload_stride);
+    ALLOC(e, e->d_one_err, 4);
+    ALLOC(e, e->d_result, sizeof(dj_sweep_result));
+    ALLOC(e, e->d_part_counts, (size_t)grid_for(nb, PART_BLOCK) * PART_MAX_RANKS * 4);
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return DJ_OK;
+}
+
+extern "C" int dj_create(const dj_config* cfg, dj_engine** out) {
+    if (!cfg || !out) return fail(nullptr, DJ_E_INVALID, "null argument");
+    if (cfg->struct_size != sizeof(dj_config)) return fail(nullptr, DJ_E_INVALID, "dj_config.struct_size mismatch");
+    if (cfg->max_count < 1 || cfg->max_count > 999) return fail(nullptr, DJ_E_INVALID, "max_count must be 1..999");
+    if (cfg->payload_stride < 64 || cfg->payload_stride % 64 || cfg->payload_stride > (1u << 20))
+        return fail(nullptr, DJ_E_INVALID, "payload_stride must be a multiple of 64 in [64, 1 MiB]");
+    if (cfg->max_batch < 1 || cfg->max_batch > (1u << 24)) return fail(nullptr, DJ_E_INVALID, "max_batch must be 1..2^24");
+    if (cfg->capacity_barriers < 1) return fail(nullptr, DJ_E_INVALID, "capacity_barriers must be positive");
+    if (cfg->max_retry_publish > 200 || cfg->max_retry_timeout_publish > 200)
+        return fail(nullptr, DJ_E_INVALID, "retry caps must be <= 200");
+    if (cfg->arena_bytes / 64 < 1 + (uint64_t)slab_units(class_of(cfg->max_count), cfg->payload_stride))
+        return fail(nullptr, DJ_E_INVALID, "arena_bytes smaller than one slab of max_count positions");
+    dj_engine* e = new (std::nothrow) dj_engine();
+    if (!e) return fail(nullptr, DJ_E_NOMEM, "out of host memory");
+    e->cfg = *cfg;
+    e->n_allocs = 0;
+    e->stream = nullptr;
+    int rc = create_impl(e);
+    if (rc != DJ_OK) {
+        g_create_err = e->err;
+        dj_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return DJ_OK;
+}
+
+extern "C" int dj_sync(dj_engine* e) {
+    if (!e) return DJ_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return DJ_OK;
+}
+
+extern "C" void* dj_stream(dj_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+// ---- hot path ----------------------------------------------------------------------------
+extern "C" int dj_fork_batch(dj_engine* e, uint32_t n, const dj_fork_rec* d_recs, int32_t* d_status) {
+    if (!e) return DJ_E_INVALID;
+    if (n == 0) return DJ_OK;
+    if (!d_recs || !d_status || !aligned16(d_recs)) return fail(e, DJ_E_INVALID, "fork: null or misaligned pointer");
+    if (n > e->cfg.max_batch) return fail(e, DJ_E_TOO_LARGE, "fork: n=%u exceeds max_batch=%u", n, e->cfg.max_batch);
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    snapshot_tails_kernel<<<1, 64, 0, e->stream>>>(e->t);
+    fork_claim_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, d_recs, n, d_status);
+    fork_apply_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, d_recs, n, d_status);
+    HIP_TRY(e, hipGetLastError());
+    return DJ_OK;
+}
+
+template <int G>
+static void launch_join_copy(dj_engine* e, uint32_t n, const dj_join_rec* recs, const uint8_t* payloads, uint64_t pitch) {
+    const uint64_t steps = ((uint64_t)n + (64 / G) - 1) / (64 / G);          // wave steps
+    uint64_t blocks = (steps + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    join_copy_kernel<G><<<(uint32_t)blocks, 256, 0, e->stream>>>(e->t, e->w, recs, payloads, pitch, n);
+}
+
+extern "C" int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs, const uint8_t* d_payloads,
+                             uint64_t pitch, uint64_t now_ms, int32_t* d_status) {
+    if (!e) return DJ_E_INVALID;
+    if (!clock_ok(now_ms)) return fail(e, DJ_E_CLOCK_RANGE, "join: now_ms=%llu outside [1e12, 9e12)", (unsigned long long)now_ms);
+    if (n == 0) return DJ_OK;
+    if (!d_recs || !d_status || !d_payloads) return fail(e, DJ_E_INVALID, "join: null pointer");
+    if (!aligned16(d_recs) || !aligned16(d_payloads) || pitch % 16 || pitch == 0)
+        return fail(e, DJ_E_INVALID, "join: records and payloads must be 16-byte aligned, pitch a positive multiple of 16");
+    if (n > e->cfg.max_batch) return fail(e, DJ_E_TOO_LARGE, "join: n=%u exceeds max_batch=%u", n, e->cfg.max_batch);
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipMemsetAsync(e->w.counters, 0, C_COUNT * 4, e->stream));
+    join_link_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, d_recs, n, pitch, d_status);
+    join_resolve_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, now_ms, d_status);
+    join_resolve_complex_kernel<<<256, 64, 0, e->stream>>>(e->t, e->w, now_ms, d_status);
+    const uint32_t lanes = e->cfg.payload_stride / 16;
+    if (lanes <= 4) launch_join_copy<4>(e, n, d_recs, d_payloads, pitch);
+    else if (lanes <= 8) launch_join_copy<8>(e, n, d_recs, d_payloads, pitch);
+    else if (lanes <= 16) launch_join_copy<16>(e, n, d_recs, d_payloads, pitch);
+    else if (lanes <= 32) launch_join_copy<32>(e, n, d_recs, d_payloads, pitch);
+    else launch_join_copy<64>(e, n, d_recs, d_payloads, pitch);
+    HIP_TRY(e, hipGetLastError());
+    return DJ_OK;
+}
+
+static uint32_t scan_blocks(const dj_engine* e) {
+    uint64_t b = (e->t.mask + 1) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (uint32_t)b;
+}
+
+static int sweep_impl(dj_engine* e, const char* what, uint64_t now_ms, uint32_t cap_conts, uint64_t cap_positions,
+                      int gather, dj_cont* d_conts, uint32_t* d_lens, uint32_t* d_max_waits, uint8_t* d_payloads,
+                      dj_sweep_result* d_result, dj_sweep_result* h_result) {
+    if (!e) return DJ_E_INVALID;
+    if (!clock_ok(now_ms)) return fail(e, DJ_E_CLOCK_RANGE, "%s: now_ms=%llu outside [1e12, 9e12)", what, (unsigned long long)now_ms);
+    if (!d_conts || cap_conts == 0) return fail(e, DJ_E_INVALID, "%s: no continuation buffer", what);
+    if (cap_conts > e->t.mask + 1) cap_conts = (uint32_t)(e->t.mask + 1);
+    if (gather) {
+        if (cap_positions < e->cfg.max_count) return fail(e, DJ_E_INVALID, "%s: cap_positions must be >= max_count", what);
+        if (d_payloads && !aligned16(d_payloads)) return fail(e, DJ_E_INVALID, "%s: payload buffer must be 16-byte aligned", what);
+    }
+    dj_sweep_result* res = d_result ? d_result : e->d_result;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipMemsetAsync(res, 0, sizeof(dj_sweep_result), e->stream));
+    pop_due_kernel<<<scan_blocks(e), 256, 0, e->stream>>>(e->t, e->w, now_ms, cap_conts, cap_positions, gather, d_conts, res);
+    finish_result_kernel<<<1, 64, 0, e->stream>>>(res, cap_conts, cap_positions, gather);
+    if (gather) {
+        uint32_t blocks = grid_for((uint64_t)cap_conts * 64, 256);
+        if (blocks > 16384) blocks = 16384;
+        gather_kernel<<<blocks, 256, 0, e->stream>>>(e->t, e->w, d_conts, res, 0, 1, d_lens, d_max_waits, d_payloads);
+    }
+    HIP_TRY(e, hipGetLastError());
+    if (h_result) {
+        HIP_TRY(e, hipMemcpyAsync(h_result, res, sizeof(dj_sweep_result), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+    }
+    return DJ_OK;
+}
+
+extern "C" int dj_pop_due(dj_engine* e, uint64_t now_ms, uint32_t cap_conts, dj_cont* d_conts,
+                          dj_sweep_result* d_result, dj_sweep_result* h_result) {
+    return sweep_impl(e, "pop_due", now_ms, cap_conts, 0, 0, d_conts, nullptr, nullptr, nullptr, d_result, h_result);
+}
+
+extern "C" int dj_sweep(dj_engine* e, uint64_t now_ms, uint32_t cap_conts, uint64_t cap_positions, dj_cont* d_conts,
+                        uint32_t* d_lens, uint32_t* d_max_waits, uint8_t* d_payloads, dj_sweep_result* d_result,
+                        dj_sweep_result* h_result) {
+    return sweep_impl(e, "sweep", now_ms, cap_conts, cap_positions, 1, d_conts, d_lens, d_max_waits, d_payloads,
+                      d_result, h_result);
+}
+
+extern "C" int dj_ack_batch(dj_engine* e, uint32_t n, const uint32_t* d_n, const dj_cont* d_conts, const uint8_t* d_ok,
+                            uint64_t now_ms, int32_t* d_status) {
+    if (!e) return DJ_E_INVALID;
+    if (!clock_ok(now_ms)) return fail(e, DJ_E_CLOCK_RANGE, "ack: now_ms=%llu outside [1e12, 9e12)", (unsigned long long)now_ms);
+    if (n == 0) return DJ_OK;
+    if (!d_conts || !d_status) return fail(e, DJ_E_INVALID, "ack: null pointer");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    snapshot_tails_kernel<<<1, 64, 0, e->stream>>>(e->t);
+    ack_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, n, d_n, d_conts, d_ok, now_ms, d_status);
+    HIP_TRY(e, hipGetLastError());
+    return DJ_OK;
+}
+
+extern "C" int dj_recover(dj_engine* e, uint64_t now_ms, uint32_t cap, dj_cont* d_conts, int32_t* d_status,
+                          dj_sweep_result* d_result, dj_sweep_result* h_result) {
+    if (!e) return DJ_E_INVALID;
+    if (!clock_ok(now_ms)) return fail(e, DJ_E_CLOCK_RANGE, "recover: now_ms=%llu outside [1e12, 9e12)", (unsigned long long)now_ms);
+    if (!d_conts || !d_status || cap == 0) return fail(e, DJ_E_INVALID, "recover: no output buffer");
+    dj_sweep_result* res = d_result ? d_result : e->d_result;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipMemsetAsync(res, 0, sizeof(dj_sweep_result), e->stream));
+    snapshot_tails_kernel<<<1, 64, 0, e->stream>>>(e->t);
+    recover_kernel<<<scan_blocks(e), 256, 0, e->stream>>>(e->t, now_ms, cap, d_conts, d_status, res);
+    finish_result_kernel<<<1, 64, 0, e->stream>>>(res, cap, 0, 0);
+    HIP_TRY(e, hipGetLastError());
+    if (h_result) {
+        HIP_TRY(e, hipMemcpyAsync(h_result, res, sizeof(dj_sweep_result), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+    }
+    return DJ_OK;
+}
+
+// ---- single-key functions ---------------------------------------------------------------
+extern "C" int dj_snapshot_one(dj_engine* e, uint64_t fp_lo, uint64_t fp_hi, int update_ts, dj_cont* h_meta,
+                               uint32_t* h_lens, uint32_t* h_max_waits, uint8_t* h_payloads) {
+    if (!e || !h_meta) return DJ_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    lookup_one_kernel<<<1, 64, 0, e->stream>>>(e->t, e->w, fp_lo, fp_hi, e->d_one_cont, e->d_one_scores);
+    gather_kernel<<<1, 64, 0, e->stream>>>(e->t, e->w, e->d_one_cont, nullptr, 1, update_ts ? 1 : 0, e->d_one_lens,
+                                           e->d_one_mws, h_payloads ? e->d_one_payload : nullptr);
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipMemcpyAsync(h_meta, e->d_one_cont, sizeof(dj_cont), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    const uint32_t count = h_meta->count;
+    if (count) {
+        if (h_lens) HIP_TRY(e, hipMemcpyAsync(h_lens, e->d_one_lens, (size_t)count * 4, hipMemcpyDeviceToHost, e->stream));
+        if (h_max_waits) HIP_TRY(e, hipMemcpyAsync(h_max_waits, e->d_one_mws, (size_t)count * 4, hipMemcpyDeviceToHost, e->stream));
+        if (h_payloads)
+            HIP_TRY(e, hipMemcpyAsync(h_payloads, e->d_one_payload, (size_t)count * e->cfg.payload_stride, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+    }
+    return DJ_OK;
+}
+
+extern "C" int dj_store_in_publish_queue(dj_engine* e, uint64_t fp_lo, uint64_t fp_hi, uint64_t at_ms) {
+    if (!e) return DJ_E_INVALID;
+    if (!clock_ok(at_ms)) return fail(e, DJ_E_CLOCK_RANGE, "store_in_publish_queue: at_ms outside [1e12, 9e12)");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    store_in_queue_one_kernel<<<1, 64, 0, e->stream>>>(e->t, fp_lo, fp_hi, at_ms, e->d_one_err);
+    HIP_TRY(e, hipGetLastError());
+    int32_t err = 0;
+    HIP_TRY(e, hipMemcpyAsync(&err, e->d_one_err, 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (err) return fail(e, DJ_E_NOMEM, "store_in_publish_queue: table full");
+    return DJ_OK;
+}
+
+extern "C" int dj_queue_scores(dj_engine* e, uint64_t fp_lo, uint64_t fp_hi, uint64_t* h_primary_at, uint64_t* h_backup_at) {
+    if (!e) return DJ_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    lookup_one_kernel<<<1, 64, 0, e->stream>>>(e->t, e->w, fp_lo, fp_hi, e->d_one_cont, e->d_one_scores);
+    HIP_TRY(e, hipGetLastError());
+    uint64_t sc[2];
+    HIP_TRY(e, hipMemcpyAsync(sc, e->d_one_scores, 16, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (h_primary_at) *h_primary_at = sc[0];
+    if (h_backup_at) *h_backup_at = sc[1];
+    return DJ_OK;
+}
+
+extern "C" int dj_get_stats(dj_engine* e, dj_stats* h_stats) {
+    if (!e || !h_stats) return DJ_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    unsigned long long st[4], bump;
+    HIP_TRY(e, hipMemcpyAsync(st, e->t.stat, sizeof st, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(&bump, e->t.bump, 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    h_stats->slots = e->t.mask + 1;
+    h_stats->live = st[0];
+    h_stats->tombstones = st[1];
+    h_stats->arena_units_used = bump;
+    h_stats->arena_units_free = st[2];
+    return DJ_OK;
+}
+
+// ---- multi-GPU routing ------------------------------------------------------------------
+template <int G>
+static void launch_gather_rows(dj_engine* e, const uint8_t* in, uint8_t* out, const uint32_t* origin, uint32_t n, uint64_t pitch) {
+    const uint64_t steps = ((uint64_t)n + (64 / G) - 1) / (64 / G);
+    uint64_t blocks = (steps + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    gather_rows_kernel<G><<<(uint32_t)blocks, 256, 0, e->stream>>>(in, out, origin, n, pitch);
+}
+
+extern "C" int dj_partition_joins(dj_engine* e, uint32_t n, uint32_t n_ranks, const dj_join_rec* d_recs,
+                                  const uint8_t* d_payloads, uint64_t pitch, dj_join_rec* d_recs_out,
+                                  uint8_t* d_payloads_out, uint32_t* d_origin, uint32_t* d_counts) {
+    if (!e) return DJ_E_INVALID;
+    if (n_ranks < 1 || n_ranks > PART_MAX_RANKS) return fail(e, DJ_E_INVALID, "partition: n_ranks must be 1..%d", PART_MAX_RANKS);
+    if (!d_recs || !d_recs_out || !d_origin || !d_counts) return fail(e, DJ_E_INVALID, "partition: null pointer");
+    if (!aligned16(d_recs) || !aligned16(d_recs_out)) return fail(e, DJ_E_INVALID, "partition: records must be 16-byte aligned");
+    if (d_payloads && (!d_payloads_out || !aligned16(d_payloads) || !aligned16(d_payloads_out) || pitch % 16 || pitch == 0))
+        return fail(e, DJ_E_INVALID, "partition: payload buffers must be 16-byte aligned, pitch a positive multiple of 16");
+    if (n > e->cfg.max_batch) return fail(e, DJ_E_TOO_LARGE, "partition: n=%u exceeds max_batch=%u", n, e->cfg.max_batch);
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    if (n == 0) {
+        HIP_TRY(e, hipMemsetAsync(d_counts, 0, n_ranks * 4, e->stream));
+        return DJ_OK;
+    }
+    const uint32_t blocks = grid_for(n, PART_BLOCK);
+    partition_count_kernel<<<blocks, PART_BLOCK, 0, e->stream>>>(d_recs, n, n_ranks, e->d_part_counts);
+    partition_scan_kernel<<<1, 1024, 0, e->stream>>>(e->d_part_counts, blocks, n_ranks, d_counts);
+    partition_scatter_kernel<<<blocks, PART_BLOCK, 0, e->stream>>>(d_recs, n, n_ranks, e->d_part_counts, d_recs_out, d_origin);
+    if (d_payloads) {
+        const uint64_t lanes = pitch / 16;
+        if (lanes <= 4) launch_gather_rows<4>(e, d_payloads, d_payloads_out, d_origin, n, pitch);
+        else if (lanes <= 8) launch_gather_rows<8>(e, d_payloads, d_payloads_out, d_origin, n, pitch);
+        else if (lanes <= 16) launch_gather_rows<16>(e, d_payloads, d_payloads_out, d_origin, n, pitch);
+        else if (lanes <= 32) launch_gather_rows<32>(e, d_payloads, d_payloads_out, d_origin, n, pitch);
+        else launch_gather_rows<64>(e, d_payloads, d_payloads_out, d_origin, n, pitch);
+    }
+    HIP_TRY(e, hipGetLastError());
+    return DJ_OK;
+}

@@ -1,0 +1,742 @@
+// dj_kernels.hpp — HIP kernels of the barrier engine (gfx950, wave64).
+//
+// Nothing here is a dense contraction: every kernel is integer / byte work bound by HBM
+// latency and bandwidth.  Citations are to the reference tree (src/distributed_join/).
+#pragma once
+#include "dj_device.hpp"
+
+namespace dj {
+
+// =====================================================================================
+// fork: redis/fork (redis.clj:90-104) + store-in-publish-queue at the deadline (core.clj:30)
+// =====================================================================================
+
+// pass 1: find or claim the slot of every record; the highest record index per slot wins
+// (a later /v1/fork of the same barrier fully resets an earlier one, redis.clj:97-103).
+__global__ void __launch_bounds__(256) fork_claim_kernel(Table t, Work w, const dj_fork_rec* recs, uint32_t n,
+                                                         int32_t* status) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const ulonglong2 a = reinterpret_cast<const ulonglong2*>(recs)[2 * (size_t)i];
+    const uint32_t count = recs[i].count;
+    if (count < 1 || count > t.max_count) {   // store.clj:32-34
+        status[i] = DJ_FORK_BAD_COUNT;
+        w.slot_of[i] = 0xFFFFFFFFu;
+        return;
+    }
+    bool created;
+    int64_t s = find_or_claim(t, a.x, a.y, &created);
+    if (s < 0) {
+        status[i] = DJ_FORK_TABLE_FULL;
+        w.slot_of[i] = 0xFFFFFFFFu;
+        return;
+    }
+    w.slot_of[i] = (uint32_t)s;
+    a_max(&t.slots[s].chain, i + 1);
+    status[i] = DJ_FORK_CREATED;
+}
+
+// pass 2: the winning record of each slot resets the barrier.
+__global__ void __launch_bounds__(256) fork_apply_kernel(Table t, Work w, const dj_fork_rec* recs, uint32_t n,
+                                                         int32_t* status) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s = w.slot_of[i];
+    if (s == 0xFFFFFFFFu) return;
+    Slot* sl = &t.slots[s];
+    if (sl->chain != i + 1) return;  // an equal barrier-id later in the batch supersedes this record
+    const dj_fork_rec r = recs[i];
+    const uint32_t k_new = class_of(r.count);
+    uint32_t slab = sl->slab;
+    if (slab == 0 || class_of(sl->count) != k_new) {
+        uint32_t fresh = slab_alloc(t, k_new);
+        if (fresh == 0) {
+            // engine limit, no counterpart in the reference: report it and leave the table as it was
+            status[i] = DJ_FORK_NO_SPACE;
+            sl->chain = 0;
+            if (!(sl->meta & META_HAS) && t.q_primary[s] == NQ && t.q_backup[s] == NQ) delete_slot(t, s);
+            return;
+        }
+        if (slab) slab_free(t, class_of(sl->count), slab);
+        slab = fresh;
+    }
+    if (r.count > 64) {
+        uint64_t* bm = slab_bitmap(t, slab);
+        for (uint32_t j = 0; j < (class_positions(k_new) >> 6); ++j) bm[j] = 0;
+    }
+    sl->count = r.count;                                  // SET <id>:metadata
+    sl->meta = meta_pack(true, RETRY_NIL, RETRY_NIL);
+    sl->slab = slab;
+    sl->chain = 0;
+    sl->deadline = r.deadline_ms;
+    sl->join_ts = 0;                                      // DEL <id>:join-ts
+    sl->join_ts_read = 0;                                 // DEL <id>:join-ts-read
+    sl->bits = 0;                                         // DEL <id>
+    t.q_backup[s] = r.deadline_ms;                        // ZREM both, then ZADD both (redis.clj:257-258)
+    t.q_primary[s] = r.deadline_ms;
+}
+
+// =====================================================================================
+// join: redis/join (redis.clj:143-159), all-there? (core.clj:36-38), queue update (core.clj:52-58)
+//
+// A batch is applied with the results of processing its events one by one in array order.
+// Pass 1 links every event into a per-barrier chain with one atomic exchange on the slot;
+// pass 2 gives each touched barrier to ONE thread, which replays its chain in array order
+// with plain loads and stores; pass 3 copies the messages that survive (last writer per
+// position, the HSET semantics of redis.clj:135).
+// =====================================================================================
+
+__global__ void __launch_bounds__(256) join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n,
+                                                        uint64_t pitch, int32_t* status) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool first = false;
+    uint32_t slot = 0;
+    if (i < n) {
+        const ulonglong2 a = reinterpret_cast<const ulonglong2*>(recs)[2 * (size_t)i];
+        const uint4 b = reinterpret_cast<const uint4*>(recs)[2 * (size_t)i + 1];  // position, len, max_wait, -
+        int32_t st = 0;
+        int64_t s = -1;
+        if (b.y > t.stride || b.y > pitch) {
+            st = DJ_JOIN_TOO_LONG;                         // store.clj:24-26
+        } else {
+            s = find_slot(t, a.x, a.y);
+            if (s < 0 || !(t.slots[s].meta & META_HAS) || t.slots[s].slab == 0) st = DJ_JOIN_NOT_FOUND;   // redis.clj:152
+            else if (b.x >= t.slots[s].count) st = DJ_JOIN_BAD_POSITION;          // redis.clj:153
+        }
+        w.dst[i] = NODST;
+        if (st != 0) {
+            status[i] = st;
+        } else {
+            uint32_t prev = a_xchg(&t.slots[s].chain, i + 1);
+            w.node[i] = node_pack(prev, b.x, b.z);
+            first = prev == 0;
+            slot = (uint32_t)s;
+        }
+    }
+    uint32_t at = wave_append(&w.counters[C_TOUCHED], first);
+    if (first) w.touched[at] = slot;
+}
+
+// Sequential replay of one barrier's events e[0..m) (sorted by array index) — the body of
+// core/join per event.  `bits`/`arrived` are the presence state, pa the primary-queue score.
+struct ReplayState {
+    uint64_t bits;      // count <= 64
+    uint32_t arrived;
+    uint32_t count;
+    uint64_t pa;        // primary score (NQ = not queued); valid when pa_loaded
+    bool pa_loaded, pa_dirty, enq;
+};
+
+__device__ inline int32_t replay_one(const Table& t, uint64_t s, uint32_t slab, ReplayState& r, uint32_t pos,
+                                     uint32_t mw, uint64_t now) {
+    if (r.count > 64) {
+        uint64_t* bm = slab_bitmap(t, slab);
+        uint64_t word = bm[pos >> 6], bit = 1ull << (pos & 63);
+        if (!(word & bit)) { bm[pos >> 6] = word | bit; ++r.arrived; }      // HSET + HLEN
+    } else {
+        uint64_t bit = 1ull << pos;
+        if (!(r.bits & bit)) { r.bits |= bit; ++r.arrived; }
+    }
+    if (r.arrived == r.count) {              // all-there?, core.clj:36-38
+        r.enq = true;                        // store-in-publish-queue at now, core.clj:54
+        return DJ_JOIN_COMPLETE;
+    }
+    if (mw) {                                // join-with-max-wait, core.clj:40-42
+        if (!r.pa_loaded) { r.pa = t.q_primary[s]; r.pa_loaded = true; }
+        if (r.pa == NQ) return DJ_JOIN_NEAREST_NOT_QUEUED;   // ZSCORE nil: the Lua compare raises (redis.clj:268-269)
+        uint64_t at = now + 1000ull * mw;
+        if (r.pa > at) { r.pa = at; r.pa_dirty = true; }     // redis.clj:269-271
+    }
+    return DJ_JOIN_WAITING;
+}
+
+constexpr int CHAIN_REG = 8;   // chains up to this length are replayed from registers
+
+__global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint64_t now, int32_t* status) {
+    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    bool is_complex = false;
+    uint32_t s = 0;
+    if (tid < w.counters[C_TOUCHED]) {
+        s = w.touched[tid];
+        Slot* sl = &t.slots[s];
+        const uint32_t count = sl->count, slab = sl->slab;
+        uint32_t cur = sl->chain;
+        // walk the chain (newest link first)
+        uint32_t idx[CHAIN_REG];
+        uint64_t nd[CHAIN_REG];
+        int m = 0;
+#pragma unroll
+        for (int k = 0; k < CHAIN_REG; ++k) {
+            idx[k] = 0xFFFFFFFFu;
+            nd[k] = 0;
+            if (cur != 0) {
+                idx[k] = cur - 1;
+                nd[k] = w.node[cur - 1];
+                cur = node_next(nd[k]);
+                ++m;
+            }
+        }
+        if (cur != 0) {
+            is_complex = true;
+        } else {
+            // sort by event index (array order); unused entries carry 0xFFFFFFFF and sink to the end
+#pragma unroll
+            for (int a = 0; a < CHAIN_REG; ++a)
+#pragma unroll
+                for (int b = 0; b + 1 < CHAIN_REG - a; ++b)
+                    if (idx[b] > idx[b + 1]) {
+                        uint32_t ti = idx[b]; idx[b] = idx[b + 1]; idx[b + 1] = ti;
+                        uint64_t tn = nd[b]; nd[b] = nd[b + 1]; nd[b + 1] = tn;
+                    }
+            ReplayState r;
+            r.count = count;
+            r.bits = count > 64 ? 0 : sl->bits;
+            r.arrived = count > 64 ? (uint32_t)sl->bits : (uint32_t)__popcll(sl->bits);
+            r.pa = NQ; r.pa_loaded = false; r.pa_dirty = false; r.enq = false;
+            const uint64_t d = dst_pack(slab, count);
+#pragma unroll
+            for (int k = 0; k < CHAIN_REG; ++k) {
+                if (k < m) {
+                    const uint32_t pos = node_pos(nd[k]);
+                    status[idx[k]] = replay_one(t, s, slab, r, pos, node_mw(nd[k]), now);
+                    bool last = true;   // last writer of its position inside the batch
+#pragma unroll
+                    for (int j = k + 1; j < CHAIN_REG; ++j)
+                        if (j < m && node_pos(nd[j]) == pos) last = false;
+                    if (last) w.dst[idx[k]] = d;
+                }
+            }
+            sl->bits = count > 64 ? (uint64_t)r.arrived : r.bits;
+            sl->join_ts = now;                              // SET <id>:join-ts, redis.clj:136
+            sl->chain = 0;
+            if (r.enq) { t.q_backup[s] = now; t.q_primary[s] = now; }          // redis.clj:257-258
+            else if (r.pa_dirty) { t.q_backup[s] = r.pa; t.q_primary[s] = r.pa; }  // redis.clj:270-271
+        }
+    }
+    uint32_t at = wave_append(&w.counters[C_COMPLEX], is_complex);
+    if (is_complex) w.complex_[at] = s;
+}
+
+// Barriers with more than CHAIN_REG events in the batch: one wave each.  The result of the
+// sequential replay is computed without sorting, from the first and last event index per
+// position: the barrier completes at T = max over newly present positions of the first
+// index touching it; events at or after T answer COMPLETE, the message of a position comes
+// from its last index.
+constexpr uint32_t IDX_NONE = 0xFFFFFFFFu;
+
+__global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work w, uint64_t now, int32_t* status) {
+    __shared__ uint32_t fmin[1024];
+    __shared__ uint32_t fmax[1024];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t nc = w.counters[C_COMPLEX];
+    for (uint32_t c = blockIdx.x; c < nc; c += gridDim.x) {
+        const uint32_t s = w.complex_[c];
+        Slot* sl = &t.slots[s];
+        const uint32_t count = sl->count, slab = sl->slab;
+        const uint32_t head = sl->chain;
+        for (uint32_t p = lane; p < 1024; p += 64) { fmin[p] = IDX_NONE; fmax[p] = 0; }
+        __syncthreads();
+        uint64_t at_min = NQ;      // smallest now + 1000*max-wait over the batch's waiting events
+        if (lane == 0) {
+            for (uint32_t cur = head; cur != 0;) {
+                const uint64_t x = w.node[cur - 1];
+                const uint32_t i = cur - 1, pos = node_pos(x);
+                if (i < fmin[pos]) fmin[pos] = i;
+                if (i + 1 > fmax[pos]) fmax[pos] = i + 1;
+                cur = node_next(x);
+            }
+        }
+        __syncthreads();
+        // newly present positions, word by word (lane j owns words j, j+64, ...)
+        uint32_t t_complete = 0, n_new = 0;
+        const uint32_t words = (count + 63) >> 6;
+        uint64_t bits0 = sl->bits;
+        for (uint32_t wd = lane; wd < words; wd += 64) {
+            uint64_t word = count > 64 ? slab_bitmap(t, slab)[wd] : bits0;
+            uint64_t add = 0;
+            for (uint32_t b = 0; b < 64 && wd * 64 + b < count; ++b) {
+                const uint32_t p = wd * 64 + b;
+                if (fmin[p] != IDX_NONE && !((word >> b) & 1)) {
+                    add |= 1ull << b;
+                    ++n_new;
+                    if (fmin[p] > t_complete) t_complete = fmin[p];
+                }
+            }
+            if (add) {
+                if (count > 64) slab_bitmap(t, slab)[wd] = word | add;
+                else bits0 = word | add;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            n_new += __shfl_xor(n_new, off);
+            uint32_t o = __shfl_xor(t_complete, off);
+            if (o > t_complete) t_complete = o;
+        }
+        bits0 = __shfl(bits0, 0);
+        if (lane == 0) {
+            const uint32_t arrived_pre = count > 64 ? (uint32_t)sl->bits : (uint32_t)__popcll(sl->bits);
+            const uint32_t arrived = arrived_pre + n_new;
+            // first event index that answers COMPLETE
+            uint32_t T = IDX_NONE;
+            if (arrived_pre == count) T = 0;
+            else if (arrived == count) T = t_complete;
+            const uint64_t pa_pre = t.q_primary[s];
+            const uint64_t d = dst_pack(slab, count);
+            for (uint32_t cur = head; cur != 0;) {
+                const uint64_t x = w.node[cur - 1];
+                const uint32_t i = cur - 1, pos = node_pos(x), mw = node_mw(x);
+                int32_t st;
+                if (i >= T && T != IDX_NONE) st = DJ_JOIN_COMPLETE;
+                else if (mw && pa_pre == NQ) st = DJ_JOIN_NEAREST_NOT_QUEUED;
+                else {
+                    st = DJ_JOIN_WAITING;
+                    if (mw) { uint64_t at = now + 1000ull * mw; if (at < at_min) at_min = at; }
+                }
+                status[i] = st;
+                if (fmax[pos] == i + 1) w.dst[i] = d;
+                cur = node_next(x);
+            }
+            sl->bits = count > 64 ? (uint64_t)arrived : bits0;
+            sl->join_ts = now;
+            sl->chain = 0;
+            if (T != IDX_NONE) { t.q_backup[s] = now; t.q_primary[s] = now; }
+            else if (pa_pre != NQ && at_min < pa_pre) { t.q_backup[s] = at_min; t.q_primary[s] = at_min; }
+        }
+        __syncthreads();
+    }
+}
+
+// pass 3: messages of surviving events into the barrier's slab.  G lanes cooperate on one
+// message with 16-byte loads and stores; a wave handles 64/G events per step.
+template <int G>
+__global__ void __launch_bounds__(256) join_copy_kernel(Table t, Work w, const dj_join_rec* recs,
+                                                        const uint8_t* payloads, uint64_t pitch, uint32_t n) {
+    constexpr int EPW = 64 / G;                       // events per wave step
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t sub = lane / G, j0 = lane % G;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t base = wave * EPW; base < n; base += waves * EPW) {
+        const uint64_t i = base + sub;
+        if (i >= n) continue;
+        const uint64_t d = w.dst[i];
+        if (d == NODST) continue;
+        const uint4 b = reinterpret_cast<const uint4*>(recs)[2 * i + 1];   // position, len, max_wait
+        const uint32_t slab = (uint32_t)d, k = class_of((uint32_t)(d >> 32));
+        if (j0 == 0) slab_posmeta(t, slab, k)[b.x] = make_uint2(b.y, b.z);
+        const uint4* src = reinterpret_cast<const uint4*>(payloads + i * pitch);
+        uint4* dstp = reinterpret_cast<uint4*>(slab_payload(t, slab, k) + (uint64_t)b.x * t.stride);
+        const uint32_t chunks = (b.y + 15) >> 4;
+        for (uint32_t c = j0; c < chunks; c += G) dstp[c] = src[c];
+    }
+}
+
+// =====================================================================================
+// sweep: redis/all-publish-messages (redis.clj:283-289) then, per popped barrier,
+// join-metadata, timeout classification (core.clj:86-95) and redis/all-joins (redis.clj:210-243)
+// =====================================================================================
+
+__device__ inline void fill_cont(dj_cont* c, const Slot& sl, uint64_t now, uint64_t publish_at, uint64_t pos_base) {
+    c->fp_lo = sl.fp_lo;
+    c->fp_hi = sl.fp_hi;
+    c->publish_at = publish_at;
+    c->pos_base = pos_base;
+    c->reserved = 0;
+    if (sl.meta & META_HAS) {
+        c->deadline_ms = sl.deadline;
+        c->count = sl.count;
+        c->flags = now > sl.deadline ? DJ_CONT_TIMEOUT : 0;     // is-timeout?, strict (core.clj:86-89)
+        c->retry_publish = retry_to_api(meta_retry_pub(sl.meta));
+        c->retry_timeout = retry_to_api(meta_retry_to(sl.meta));
+    } else {
+        c->deadline_ms = 0;
+        c->count = 0;
+        c->flags = DJ_CONT_NO_METADATA;
+        c->retry_publish = DJ_NIL;
+        c->retry_timeout = DJ_NIL;
+    }
+}
+
+// One pass over q_primary: every slot with score <= now is popped (ZRANGEBYSCORE +
+// ZREMRANGEBYSCORE 0 now).  Output indices come from one atomic pair per wave (ballot +
+// in-wave prefix sum).  res->n_conts / n_positions are the raw cursors until
+// finish_result_kernel clamps them.
+__global__ void __launch_bounds__(256) pop_due_kernel(Table t, Work w, uint64_t now, uint32_t cap_conts,
+                                                      uint64_t cap_pos, int alloc_pos, dj_cont* conts,
+                                                      dj_sweep_result* res) {
+    const uint64_t nslots = t.mask + 1;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t lane = threadIdx.x & 63;
+    // all lanes of a wave iterate together (nslots is a multiple of 64)
+    for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < nslots; s += stride) {
+        const uint64_t pa = t.q_primary[s];
+        const bool due = pa <= now;
+        const uint64_t m = __ballot(due);
+        if (m == 0) continue;
+        uint32_t cnt = 0;
+        Slot sl;
+        if (due) {
+            sl = t.slots[s];
+            cnt = (sl.meta & META_HAS) ? sl.count : 0;
+        }
+        // in-wave exclusive prefix sum of the position counts
+        uint32_t incl = cnt;
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t v = __shfl_up(incl, off);
+            if ((int)lane >= off) incl += v;
+        }
+        const uint32_t total_pos = __shfl(incl, 63);
+        const int leader = __ffsll((unsigned long long)m) - 1;
+        uint32_t base_c = 0;
+        unsigned long long base_p = 0;
+        if ((int)lane == leader) {
+            base_c = a_add(&res->n_conts, (uint32_t)__popcll(m));
+            if (alloc_pos) base_p = a_add((unsigned long long*)&res->n_positions, (unsigned long long)total_pos);
+        }
+        base_c = __shfl(base_c, leader);
+        base_p = __shfl(base_p, leader);
+        if (!due) continue;
+        const uint32_t my_c = base_c + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        const uint64_t my_p = base_p + (incl - cnt);
+        if (my_c >= cap_conts) { res->more = 1; continue; }
+        if (alloc_pos && my_p + cnt > cap_pos) {
+            res->more = 1;
+            conts[my_c].flags = CONT_VOID;      // index taken, barrier stays queued
+            conts[my_c].count = 0;
+            w.cont_slot[my_c] = 0xFFFFFFFFu;
+            continue;
+        }
+        t.q_primary[s] = NQ;                    // popped; the backup entry stays (redis.clj:288)
+        fill_cont(&conts[my_c], sl, now, pa, my_p);
+        w.cont_slot[my_c] = (uint32_t)s;
+    }
+}
+
+__global__ void finish_result_kernel(dj_sweep_result* res, uint32_t cap_conts, uint64_t cap_pos, int alloc_pos) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (res->n_conts > cap_conts) res->n_conts = cap_conts;
+        if (alloc_pos && res->n_positions > cap_pos) res->n_positions = cap_pos;
+    }
+}
+
+// redis/all-joins for the popped barriers: one wave per continuation.
+// update_ts: join-ts-read := join-ts (redis.clj:222-229).
+__global__ void __launch_bounds__(256) gather_kernel(Table t, Work w, const dj_cont* conts,
+                                                     const dj_sweep_result* res, uint32_t n_fixed, int update_ts,
+                                                     uint32_t* lens, uint32_t* max_waits, uint8_t* payloads) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t n = res ? res->n_conts : n_fixed;
+    const uint32_t G = t.stride / 16 < 64 ? t.stride / 16 : 64;   // lanes per message (stride is a multiple of 64)
+    const uint32_t rows_per_step = 64 / G;
+    for (uint64_t kc = wave; kc < n; kc += waves) {
+        const uint32_t s = w.cont_slot[kc];
+        if (s == 0xFFFFFFFFu) continue;
+        const dj_cont c = conts[kc];
+        if (c.flags & (DJ_CONT_NO_METADATA | CONT_VOID)) continue;
+        Slot* sl = &t.slots[s];
+        if (update_ts && lane == 0) sl->join_ts_read = sl->join_ts;
+        const uint32_t count = c.count, slab = sl->slab, k = class_of(count);
+        const uint64_t bits0 = sl->bits;
+        const uint64_t* bm = slab_bitmap(t, slab);
+        const uint2* pm = slab_posmeta(t, slab, k);
+        const uint8_t* pay = slab_payload(t, slab, k);
+        for (uint32_t p = lane; p < count; p += 64) {
+            const bool present = count > 64 ? ((bm[p >> 6] >> (p & 63)) & 1) : ((bits0 >> p) & 1);
+            const uint2 meta = present ? pm[p] : make_uint2(DJ_NIL, 0);
+            if (lens) lens[c.pos_base + p] = meta.x;
+            if (max_waits) max_waits[c.pos_base + p] = meta.y;
+        }
+        if (!payloads) continue;
+        const uint32_t sub = lane / G, j0 = lane % G;
+        for (uint32_t p0 = 0; p0 < count; p0 += rows_per_step) {
+            const uint32_t p = p0 + sub;
+            if (p >= count) continue;
+            const bool present = count > 64 ? ((bm[p >> 6] >> (p & 63)) & 1) : ((bits0 >> p) & 1);
+            if (!present) continue;
+            const uint32_t chunks = (pm[p].x + 15) >> 4;
+            const uint4* src = reinterpret_cast<const uint4*>(pay + (uint64_t)p * t.stride);
+            uint4* dstp = reinterpret_cast<uint4*>(payloads + (c.pos_base + p) * (uint64_t)t.stride);
+            for (uint32_t ch = j0; ch < chunks; ch += G) dstp[ch] = src[ch];
+        }
+    }
+}
+
+// =====================================================================================
+// ack / recover: core/complete (core.clj:119-130), reset-publish (core.clj:113-117),
+// attempt-retry-publish (core.clj:132-155)
+// =====================================================================================
+
+// core/complete on a slot this thread owns: redis/complete (Lua, redis.clj:177-188) and on
+// "Join Updated" reset-publish.  Returns true when the barrier was deleted.
+__device__ inline bool complete_slot(const Table& t, uint64_t s, uint64_t now) {
+    Slot* sl = &t.slots[s];
+    if (sl->join_ts == sl->join_ts_read) {          // two nils compare equal
+        delete_slot(t, s);
+        return true;
+    }
+    // reset-publish: both retry counters dropped, :publish-retry-cnt 0, re-queued at now
+    sl->meta = meta_pack(sl->meta & META_HAS, 0, RETRY_NIL);
+    t.q_backup[s] = now;
+    t.q_primary[s] = now;
+    return false;
+}
+
+// retry bookkeeping shared by the publish-failure path (snapshot metadata) and the recover
+// path (fresh metadata): returns the DJ_ACK_* outcome.
+__device__ inline int32_t retry_or_drop(const Table& t, uint64_t s, uint64_t deadline, uint32_t rp, uint32_t rt,
+                                        uint64_t now) {
+    const bool timeout = now > deadline;                                  // core.clj:137
+    const uint32_t cur = timeout ? rt : rp;
+    const uint32_t cnt = cur == RETRY_NIL ? 0 : cur;                      // core.clj:139
+    const uint32_t max = timeout ? t.max_retry_timeout_publish : t.max_retry_publish;
+    if (cnt >= max)                                                       // core.clj:142-147
+        return complete_slot(t, s, now) ? DJ_ACK_DROPPED_EXHAUSTED : DJ_ACK_REQUEUED_DIRTY;
+    Slot* sl = &t.slots[s];
+    if (timeout) rt = cnt + 1; else rp = cnt + 1;                         // core.clj:151
+    sl->meta = meta_pack(true, rp, rt);
+    t.q_backup[s] = now;
+    t.q_primary[s] = now;
+    return DJ_ACK_RETRY;
+}
+
+__global__ void __launch_bounds__(256) ack_kernel(Table t, uint32_t n_max, const uint32_t* d_n, const dj_cont* conts,
+                                                  const uint8_t* ok, uint64_t now, int32_t* status) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n = d_n ? (*d_n < n_max ? *d_n : n_max) : n_max;
+    if (i >= n) return;
+    const dj_cont c = conts[i];
+    if (c.flags & CONT_VOID) { status[i] = 0; return; }
+    const bool published = ok == nullptr || ok[i] != 0;
+    const bool has_md = !(c.flags & DJ_CONT_NO_METADATA);
+    if (!has_md || published) {
+        // core.clj:159-161 / 134-136 (no metadata) or core.clj:168 (published): complete
+        int64_t s = find_slot(t, c.fp_lo, c.fp_hi);
+        bool deleted = s < 0 ? true : complete_slot(t, (uint64_t)s, now);
+        status[i] = !deleted ? DJ_ACK_REQUEUED_DIRTY : (has_md ? DJ_ACK_DONE : DJ_ACK_DONE_NO_METADATA);
+        return;
+    }
+    // publish failed: attempt-retry-publish with the metadata the publisher holds (the snapshot)
+    const uint32_t rp = retry_from_api(c.retry_publish), rt = retry_from_api(c.retry_timeout);
+    const bool timeout = now > c.deadline_ms;
+    const uint32_t cur = timeout ? rt : rp;
+    const uint32_t cnt = cur == RETRY_NIL ? 0 : cur;
+    const uint32_t max = timeout ? t.max_retry_timeout_publish : t.max_retry_publish;
+    if (cnt >= max) {
+        int64_t s = find_slot(t, c.fp_lo, c.fp_hi);
+        bool deleted = s < 0 ? true : complete_slot(t, (uint64_t)s, now);
+        status[i] = deleted ? DJ_ACK_DROPPED_EXHAUSTED : DJ_ACK_REQUEUED_DIRTY;
+        return;
+    }
+    // update-metadata writes the snapshot back (redis.clj:106-111), creating the key if the
+    // barrier was deleted meanwhile, then store-in-publish-queue at now (core.clj:110-111)
+    bool created;
+    int64_t s = find_or_claim(t, c.fp_lo, c.fp_hi, &created);
+    if (s < 0) { status[i] = 0; return; }
+    Slot* sl = &t.slots[s];
+    if (created) {
+        sl->count = 0; sl->meta = 0; sl->slab = 0; sl->chain = 0;
+        sl->deadline = 0; sl->join_ts = 0; sl->join_ts_read = 0; sl->bits = 0;
+    }
+    if (sl->count != c.count) {
+        // the snapshot's :count differs from the live one (barrier re-forked or deleted while its
+        // publish was in flight): positions at or beyond the new count are dropped
+        const uint32_t k_new = class_of(c.count);
+        if (sl->slab == 0 || class_of(sl->count) != k_new) {
+            if (sl->slab) slab_free(t, class_of(sl->count), sl->slab);
+            sl->slab = slab_alloc(t, k_new);
+            sl->bits = 0;
+            if (c.count > 64 && sl->slab) {
+                uint64_t* bm = slab_bitmap(t, sl->slab);
+                for (uint32_t j = 0; j < (class_positions(k_new) >> 6); ++j) bm[j] = 0;
+            }
+        } else if (c.count <= 64) {
+            sl->bits &= c.count == 64 ? ~0ull : ((1ull << c.count) - 1);
+        }
+        sl->count = c.count;
+    }
+    sl->deadline = c.deadline_ms;
+    status[i] = retry_or_drop(t, (uint64_t)s, c.deadline_ms, rp, rt, now);
+}
+
+// core/recover-unprocessed-publish-messages: ZRANGEBYSCORE backup 0 (now - delay), then the
+// 2-arity attempt-retry-publish with freshly read metadata (core.clj:153-155,193-201)
+__global__ void __launch_bounds__(256) recover_kernel(Table t, uint64_t now, uint32_t cap, dj_cont* conts,
+                                                      int32_t* status, dj_sweep_result* res) {
+    const uint64_t nslots = t.mask + 1;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t max_score = now - t.check_publish_delay_ms;
+    for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < nslots; s += stride) {
+        const uint64_t ba = t.q_backup[s];
+        const bool due = ba <= max_score;
+        const uint32_t at = wave_append(&res->n_conts, due);
+        if (!due) continue;
+        Slot sl = t.slots[s];
+        int32_t st;
+        if (!(sl.meta & META_HAS)) {
+            st = complete_slot(t, s, now) ? DJ_ACK_DONE_NO_METADATA : DJ_ACK_REQUEUED_DIRTY;   // core.clj:134-136
+        } else {
+            st = retry_or_drop(t, s, sl.deadline, meta_retry_pub(sl.meta), meta_retry_to(sl.meta), now);
+        }
+        if (at < cap) {
+            fill_cont(&conts[at], sl, now, ba, 0);
+            status[at] = st;
+        } else {
+            res->more = 1;
+        }
+    }
+}
+
+// =====================================================================================
+// single-key helpers
+// =====================================================================================
+
+// probe one fingerprint and describe it as a continuation (no queue change)
+__global__ void lookup_one_kernel(Table t, Work w, uint64_t lo, uint64_t hi, dj_cont* cont, uint64_t* scores) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int64_t s = find_slot(t, lo, hi);
+    scores[0] = NQ;
+    scores[1] = NQ;
+    if (s < 0) {
+        Slot none = {};
+        none.fp_lo = lo;
+        none.fp_hi = hi;
+        fill_cont(cont, none, 0, NQ, 0);
+        w.cont_slot[0] = 0xFFFFFFFFu;
+        return;
+    }
+    fill_cont(cont, t.slots[s], 0, t.q_primary[s], 0);
+    cont->flags &= ~DJ_CONT_TIMEOUT;
+    w.cont_slot[0] = (uint32_t)s;
+    scores[0] = t.q_primary[s];
+    scores[1] = t.q_backup[s];
+}
+
+// redis/store-in-publish-queue for one id (redis.clj:255-259); creates a metadata-less slot
+// when the id is unknown (a queue entry without metadata, core.clj:159-161)
+__global__ void store_in_queue_one_kernel(Table t, uint64_t lo, uint64_t hi, uint64_t at, int32_t* err) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    bool created;
+    int64_t s = find_or_claim(t, lo, hi, &created);
+    if (s < 0) { *err = 1; return; }
+    if (created) {
+        Slot* sl = &t.slots[s];
+        sl->count = 0; sl->meta = 0; sl->slab = 0; sl->chain = 0;
+        sl->deadline = 0; sl->join_ts = 0; sl->join_ts_read = 0; sl->bits = 0;
+    }
+    t.q_backup[s] = at;
+    t.q_primary[s] = at;
+    *err = 0;
+}
+
+__global__ void snapshot_tails_kernel(Table t) {
+    if (threadIdx.x < NUM_CLASSES && blockIdx.x == 0) t.ring_tail_snap[threadIdx.x] = t.ring_tail[threadIdx.x];
+}
+
+// =====================================================================================
+// multi-GPU routing: stable partition of a join batch by owner rank
+// =====================================================================================
+__host__ __device__ inline uint32_t owner_of(uint64_t lo, uint64_t hi, uint32_t n_ranks) {
+    (void)lo;
+    return (uint32_t)((hi >> 17) % n_ranks);
+}
+
+constexpr int PART_BLOCK = 256;
+constexpr int PART_MAX_RANKS = 64;
+
+// counts[b * n_ranks + r] = events of block b owned by rank r
+__global__ void __launch_bounds__(PART_BLOCK) partition_count_kernel(const dj_join_rec* recs, uint32_t n,
+                                                                     uint32_t n_ranks, uint32_t* block_counts) {
+    __shared__ uint32_t cnt[PART_MAX_RANKS];
+    if (threadIdx.x < PART_MAX_RANKS) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t i = blockIdx.x * PART_BLOCK + threadIdx.x;
+    if (i < n) {
+        const ulonglong2 a = reinterpret_cast<const ulonglong2*>(recs)[2 * (size_t)i];
+        atomicAdd(&cnt[owner_of(a.x, a.y, n_ranks)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < n_ranks) block_counts[blockIdx.x * n_ranks + threadIdx.x] = cnt[threadIdx.x];
+}
+
+// one block: exclusive scan in (rank, block) order; totals per rank to counts_out
+__global__ void __launch_bounds__(1024) partition_scan_kernel(uint32_t* block_counts, uint32_t n_blocks,
+                                                              uint32_t n_ranks, uint32_t* counts_out) {
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t r = 0; r < n_ranks; ++r) {
+        const uint32_t start = carry;
+        for (uint32_t b0 = 0; b0 < n_blocks; b0 += 1024) {
+            const uint32_t b = b0 + threadIdx.x;
+            const uint32_t v = b < n_blocks ? block_counts[b * n_ranks + r] : 0;
+            part[threadIdx.x] = v;
+            __syncthreads();
+            for (uint32_t off = 1; off < 1024; off <<= 1) {
+                uint32_t x = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+                __syncthreads();
+                part[threadIdx.x] += x;
+                __syncthreads();
+            }
+            if (b < n_blocks) block_counts[b * n_ranks + r] = carry + part[threadIdx.x] - v;
+            __syncthreads();
+            if (threadIdx.x == 1023) carry += part[1023];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) counts_out[r] = carry - start;
+        __syncthreads();
+    }
+}
+
+// scatter records (and the origin index) to their rank group, keeping array order inside a group
+__global__ void __launch_bounds__(PART_BLOCK) partition_scatter_kernel(const dj_join_rec* recs, uint32_t n,
+                                                                       uint32_t n_ranks, const uint32_t* block_offsets,
+                                                                       dj_join_rec* recs_out, uint32_t* origin) {
+    __shared__ uint32_t wave_cnt[PART_BLOCK / 64][PART_MAX_RANKS];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t i = blockIdx.x * PART_BLOCK + threadIdx.x;
+    uint32_t owner = 0xFFFFFFFFu;
+    ulonglong2 a, b;
+    if (i < n) {
+        a = reinterpret_cast<const ulonglong2*>(recs)[2 * (size_t)i];
+        b = reinterpret_cast<const ulonglong2*>(recs)[2 * (size_t)i + 1];
+        owner = owner_of(a.x, a.y, n_ranks);
+    }
+    uint32_t rank_in_wave = 0;
+    for (uint32_t r = 0; r < n_ranks; ++r) {
+        const uint64_t m = __ballot(owner == r);
+        if (owner == r) rank_in_wave = (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        if (lane == 0) wave_cnt[wv][r] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (i < n) {
+        uint32_t before = 0;
+        for (uint32_t v = 0; v < wv; ++v) before += wave_cnt[v][owner];
+        const uint32_t o = block_offsets[blockIdx.x * n_ranks + owner] + before + rank_in_wave;
+        reinterpret_cast<ulonglong2*>(recs_out)[2 * (size_t)o] = a;
+        reinterpret_cast<ulonglong2*>(recs_out)[2 * (size_t)o + 1] = b;
+        origin[o] = i;
+    }
+}
+
+// row gather: out row j = in row origin[j]; G lanes per row, 16 bytes per lane
+template <int G>
+__global__ void __launch_bounds__(256) gather_rows_kernel(const uint8_t* in, uint8_t* out, const uint32_t* origin,
+                                                          uint32_t n, uint64_t pitch) {
+    constexpr int RPW = 64 / G;
+    const uint32_t lane = threadIdx.x & 63, sub = lane / G, j0 = lane % G;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t chunks = (uint32_t)(pitch >> 4);
+    for (uint64_t base = wave * RPW; base < n; base += waves * RPW) {
+        const uint64_t j = base + sub;
+        if (j >= n) continue;
+        const uint4* src = reinterpret_cast<const uint4*>(in + (uint64_t)origin[j] * pitch);
+        uint4* dstp = reinterpret_cast<uint4*>(out + j * pitch);
+        for (uint32_t c = j0; c < chunks; c += G) dstp[c] = src[c];
+    }
+}
+
+}  // namespace dj

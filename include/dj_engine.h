@@ -1,0 +1,244 @@
+/*
+ * dj_engine.h — C ABI of the MI355X barrier engine.
+ *
+ * The engine replaces the state half of the reference service: the namespace
+ * distributed-join.redis (reference src/distributed_join/redis.clj), which is the
+ * only way src/distributed_join/core.clj touches barrier state.  One engine owns one
+ * GPU: a device-resident open-addressing barrier table in HBM, per-barrier position
+ * bitmaps and payload slabs, and the primary / backup publish queues as two
+ * per-slot score arrays.  Every call is a batch; per-item results come back in
+ * caller-provided arrays.
+ *
+ * Conventions
+ *  - plain C, no exceptions across the boundary; every function returns 0 on
+ *    success or a negative DJ_E_* code, and dj_last_error() gives the text.
+ *  - pointers named d_* are DEVICE pointers (hipMalloc memory on the engine's
+ *    device); pointers named h_* are host pointers.  The engine never frees or keeps
+ *    caller buffers past the call's completion on its stream.
+ *  - calls are asynchronous on the engine's HIP stream unless documented
+ *    otherwise; dj_sync() waits for them.  Calls on one engine must be serialised
+ *    by the caller (one engine = one stream = one mutex on the caller's side).
+ *  - the engine never reads a clock: now_ms is always an argument.  It must be a
+ *    13-digit epoch-milliseconds value (1e12 <= now_ms < 9e12): inside that range
+ *    the reference's Lua string comparison of scores (redis.clj:268-269) equals the
+ *    numeric comparison the engine performs.
+ *  - barriers are keyed by a 128-bit fingerprint of the barrier-id bytes
+ *    "join-id~transaction-id" (redis.clj:42-47); dj_fingerprint() computes it.  The id
+ *    strings and destination URLs stay on the host, keyed by fingerprint.
+ */
+#ifndef DJ_ENGINE_H
+#define DJ_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dj_engine dj_engine;
+
+/* ---- error codes (function return values) ------------------------------------ */
+#define DJ_OK              0
+#define DJ_E_INVALID      -1   /* bad argument / config */
+#define DJ_E_HIP          -2   /* a HIP runtime call failed */
+#define DJ_E_NOMEM        -3   /* device allocation failed */
+#define DJ_E_CLOCK_RANGE  -4   /* now_ms outside [1e12, 9e12) */
+#define DJ_E_TOO_LARGE    -5   /* batch larger than dj_config.max_batch */
+
+/* "absent" marker for optional 32-bit fields (nil in the reference's maps) */
+#define DJ_NIL 0xFFFFFFFFu
+/* score of a barrier that is not in a queue */
+#define DJ_NOT_QUEUED 0xFFFFFFFFFFFFFFFFull
+
+/* ---- per-item status codes ----------------------------------------------------- */
+/* dj_join_batch: what core/join (core.clj:44-58) answers for the event            */
+#define DJ_JOIN_WAITING             1  /* 202 "...waiting on more chunks."          core.clj:58  */
+#define DJ_JOIN_COMPLETE            2  /* 202 "...request will be completed."       core.clj:55  */
+#define DJ_JOIN_NOT_FOUND           3  /* 404 "barrier-id does not exist"           redis.clj:152,159 */
+#define DJ_JOIN_BAD_POSITION        4  /* 400 "position is greater than total"      redis.clj:153 */
+#define DJ_JOIN_NEAREST_NOT_QUEUED  5  /* 500: join carried max-wait while the barrier was not in the
+                                          primary queue; the Lua compare at redis.clj:269 raises, after
+                                          the position was already stored                           */
+#define DJ_JOIN_TOO_LONG            6  /* 400: message longer than dj_config.payload_stride
+                                          (store.clj:24-26 with the engine's own limit)             */
+/* dj_fork_batch: core/fork (core.clj:24-33) */
+#define DJ_FORK_CREATED             1  /* 201, barrier created or fully reset (redis.clj:90-104)    */
+#define DJ_FORK_TABLE_FULL          2  /* engine limit: no free table slot                          */
+#define DJ_FORK_NO_SPACE            3  /* engine limit: payload arena exhausted                     */
+#define DJ_FORK_BAD_COUNT           4  /* count outside 1..dj_config.max_count (store.clj:32-34)    */
+/* dj_ack_batch / dj_recover: what core/complete, reset-publish and attempt-retry-publish did      */
+#define DJ_ACK_DONE                 1  /* redis/complete deleted the barrier        redis.clj:179-185 */
+#define DJ_ACK_REQUEUED_DIRTY       2  /* a join arrived after the snapshot: reset-publish core.clj:113-117,127-129 */
+#define DJ_ACK_RETRY                3  /* retry counter +1, re-queued at now        core.clj:148-152 */
+#define DJ_ACK_DROPPED_EXHAUSTED    4  /* retries exhausted, barrier deleted        core.clj:142-147 */
+#define DJ_ACK_DONE_NO_METADATA     5  /* metadata was missing: completed as failed core.clj:134-136,159-161 */
+
+/* ---- records ------------------------------------------------------------------- */
+
+typedef struct dj_config {
+    uint32_t struct_size;               /* = sizeof(dj_config) */
+    int32_t  device;                    /* HIP device ordinal */
+    uint64_t capacity_barriers;         /* max live barriers; table slots = next pow2 >= 2x */
+    uint64_t arena_bytes;               /* payload arena size in bytes */
+    uint32_t max_count;                 /* :fork-count-max, <= 999 (config.edn:33) */
+    uint32_t payload_stride;            /* bytes reserved per position; multiple of 64; max message bytes */
+    uint32_t max_batch;                 /* largest n accepted by one batch call, <= 2^24 */
+    uint32_t max_retry_publish;         /* :max-retry-post-publish          (config.edn:24) */
+    uint32_t max_retry_timeout_publish; /* :max-retry-post-timeout-publish  (config.edn:25) */
+    uint32_t reserved0;
+    uint64_t check_publish_delay_ms;    /* :check-publish-delay-ms          (config.edn:16) */
+} dj_config;
+
+/* one /v1/fork after core/fork computed the deadline (core.clj:28): 32 bytes */
+typedef struct dj_fork_rec {
+    uint64_t fp_lo, fp_hi;      /* fingerprint of "join-id~transaction-id" */
+    uint32_t count;             /* :count */
+    uint32_t reserved;
+    uint64_t deadline_ms;       /* :timeout-secs = now + 1000 * max-wait (absolute epoch ms) */
+} dj_fork_rec;
+
+/* one /v1/join (store.clj:19-28): 32-byte event header; the message bytes of event i
+ * are at d_payloads + i * pitch */
+typedef struct dj_join_rec {
+    uint64_t fp_lo, fp_hi;      /* fingerprint of :barrier-id */
+    uint32_t position;          /* :position */
+    uint32_t len;               /* message length in bytes */
+    uint32_t max_wait_s;        /* :max-wait in seconds, 0 = absent */
+    uint32_t reserved;
+} dj_join_rec;
+
+#define DJ_CONT_TIMEOUT      1u /* now > :timeout-secs, strict (core.clj:86-89): goes to :timeout-destination */
+#define DJ_CONT_NO_METADATA  2u /* id was queued but has no metadata (core.clj:159-161) */
+
+/* one popped barrier = one continuation to publish: 64 bytes.  It doubles as the
+ * metadata snapshot that core/publish-message holds while it publishes
+ * (core.clj:175-177) and hands to attempt-retry-publish on failure (core.clj:167,170). */
+typedef struct dj_cont {
+    uint64_t fp_lo, fp_hi;
+    uint64_t deadline_ms;       /* :timeout-secs of the snapshot */
+    uint64_t publish_at;        /* the primary-queue score it was popped with */
+    uint32_t count;             /* :count of the snapshot, 0 with DJ_CONT_NO_METADATA */
+    uint32_t flags;             /* DJ_CONT_* */
+    uint32_t retry_publish;     /* :publish-retry-cnt, DJ_NIL when absent */
+    uint32_t retry_timeout;     /* :timeout-publish-retry-cnt, DJ_NIL when absent */
+    uint64_t pos_base;          /* index of position 0 of this barrier in d_lens / d_max_waits;
+                                   its message bytes start at d_payloads + pos_base * payload_stride */
+    uint64_t reserved;
+} dj_cont;
+
+/* counters a sweep leaves behind (device memory, also copied to the host on request) */
+typedef struct dj_sweep_result {
+    uint32_t n_conts;           /* continuations written */
+    uint32_t more;              /* 1: due barriers were left queued because an output cap was hit */
+    uint64_t n_positions;       /* positions written (sum of counts) */
+} dj_sweep_result;
+
+/* ---- lifecycle ------------------------------------------------------------------ */
+int  dj_create(const dj_config* cfg, dj_engine** out);
+void dj_destroy(dj_engine* e);
+const char* dj_last_error(const dj_engine* e);   /* e may be NULL: last create error */
+int  dj_sync(dj_engine* e);                        /* wait for all queued work */
+void* dj_stream(dj_engine* e);                     /* the engine's hipStream_t */
+
+/* Fingerprint of a barrier-id (host side, pure function).  Never yields a reserved
+ * value.  Replaces the Redis key strings built by make-key (redis.clj:42-47). */
+void dj_fingerprint(const void* id, size_t len, uint64_t* fp_lo, uint64_t* fp_hi);
+/* Same for n ids stored back to back; offsets has n+1 entries. */
+void dj_fingerprint_batch(const uint8_t* bytes, const uint64_t* offsets, size_t n, uint64_t* fp_lo_hi);
+
+/* ---- hot path (device pointers) ------------------------------------------------- */
+
+/* core/fork for n barriers: redis/fork (redis.clj:90-104: set metadata, drop joins and both
+ * join timestamps, remove from both queues) followed by redis/store-in-publish-queue at the
+ * deadline (core.clj:30, redis.clj:255-259).  Records are applied in array order. */
+int dj_fork_batch(dj_engine* e, uint32_t n, const dj_fork_rec* d_recs, int32_t* d_status);
+
+/* core/join for n events, applied in array order with one timestamp: redis/join
+ * (redis.clj:143-159, Lua add-join-and-count-them redis.clj:122-141), all-there?
+ * (core.clj:36-38), then store-in-publish-queue at now (core.clj:54) or, for a join with
+ * max-wait, store-nearest-in-publish-queue at now + 1000*max-wait (core.clj:40-42,
+ * redis.clj:261-281).  pitch: bytes between consecutive events' messages, multiple of 16. */
+int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs,
+                  const uint8_t* d_payloads, uint64_t pitch, uint64_t now_ms, int32_t* d_status);
+
+/* redis/all-publish-messages (redis.clj:283-289): pop every barrier whose primary score is
+ * <= now_ms; the backup entry stays.  Writes fp, publish_at (and the metadata snapshot) of at
+ * most cap_conts barriers; d_result->more says whether some were left.  Order unspecified. */
+int dj_pop_due(dj_engine* e, uint64_t now_ms, uint32_t cap_conts,
+               dj_cont* d_conts, dj_sweep_result* d_result, dj_sweep_result* h_result);
+
+/* The publisher's read side for one poll, core/process-publish-messages up to the POST
+ * (core.clj:180-188): pop (as dj_pop_due), then per popped barrier join-metadata
+ * (redis.clj:248-253), timeout classification (core.clj:86-95), and redis/all-joins
+ * (redis.clj:210-243): join-ts-read := join-ts, messages gathered in position order.
+ * Position p of continuation k: d_lens[pos_base+p] = message length or DJ_NIL when the
+ * position is missing; d_max_waits[...] = its :max-wait (0 absent; may be NULL);
+ * bytes at d_payloads + (pos_base+p) * payload_stride.  A barrier is popped only if its
+ * count still fits under cap_positions.  h_result (optional) makes the call synchronous. */
+int dj_sweep(dj_engine* e, uint64_t now_ms, uint32_t cap_conts, uint64_t cap_positions,
+             dj_cont* d_conts, uint32_t* d_lens, uint32_t* d_max_waits, uint8_t* d_payloads,
+             dj_sweep_result* d_result, dj_sweep_result* h_result);
+
+/* Outcome of publishing, for n (or *d_n when d_n != NULL, then n is the upper bound)
+ * continuations previously returned by dj_sweep / dj_pop_due; d_ok[i] != 0 (or d_ok == NULL)
+ * means the POST succeeded.
+ *   ok   -> core/complete (core.clj:119-130): redis/complete (Lua complete-if-no-update,
+ *           redis.clj:162-205) deletes the barrier unless a join arrived after the snapshot,
+ *           in which case reset-publish (core.clj:113-117) re-queues it at now_ms.
+ *   fail -> attempt-retry-publish with the snapshot (core.clj:132-152).
+ * The same barrier must not appear twice in one call. */
+int dj_ack_batch(dj_engine* e, uint32_t n, const uint32_t* d_n, const dj_cont* d_conts,
+                 const uint8_t* d_ok, uint64_t now_ms, int32_t* d_status);
+
+/* core/recover-unprocessed-publish-messages (core.clj:193-201): every backup entry with score
+ * <= now_ms - check_publish_delay_ms (redis.clj:291-293) goes through the 2-arity
+ * attempt-retry-publish (core.clj:153-155) with freshly read metadata.  Writes fp and outcome
+ * of at most cap entries (d_conts[i].fp_*, d_status[i]); all due entries are processed. */
+int dj_recover(dj_engine* e, uint64_t now_ms, uint32_t cap, dj_cont* d_conts, int32_t* d_status,
+               dj_sweep_result* d_result, dj_sweep_result* h_result);
+
+/* ---- single-key store functions (host pointers, synchronous, low rate) ----------- */
+
+/* core/status read side (core.clj:60-68): join-metadata + all-joins-status (redis.clj:245-246,
+ * no timestamp update), or with update_ts != 0 redis/all-joins (redis.clj:242-243).
+ * Returns 0 and fills *h_meta (flags has DJ_CONT_NO_METADATA when the id has no metadata;
+ * pos_base = 0); h_lens / h_max_waits need max_count entries, h_payloads max_count *
+ * payload_stride bytes (any of the three may be NULL). */
+int dj_snapshot_one(dj_engine* e, uint64_t fp_lo, uint64_t fp_hi, int update_ts,
+                    dj_cont* h_meta, uint32_t* h_lens, uint32_t* h_max_waits, uint8_t* h_payloads);
+
+/* redis/store-in-publish-queue (redis.clj:255-259) for one id, with or without metadata. */
+int dj_store_in_publish_queue(dj_engine* e, uint64_t fp_lo, uint64_t fp_hi, uint64_t at_ms);
+/* redis/get-publish-date (redis.clj:295-297) and the backup score: DJ_NOT_QUEUED when absent. */
+int dj_queue_scores(dj_engine* e, uint64_t fp_lo, uint64_t fp_hi,
+                    uint64_t* h_primary_at, uint64_t* h_backup_at);
+
+/* table occupancy, for monitoring and tests */
+typedef struct dj_stats {
+    uint64_t slots;             /* table slots */
+    uint64_t live;              /* slots holding a barrier or an orphan queue entry */
+    uint64_t tombstones;
+    uint64_t arena_units_used;  /* 64-byte units handed out by the bump pointer */
+    uint64_t arena_units_free;  /* 64-byte units sitting in the free lists */
+} dj_stats;
+int dj_get_stats(dj_engine* e, dj_stats* h_stats);
+
+/* ---- multi-GPU routing helper (device pointers) ---------------------------------- */
+
+/* owner rank of a barrier among n_ranks engines */
+uint32_t dj_owner_of(uint64_t fp_lo, uint64_t fp_hi, uint32_t n_ranks);
+
+/* Stable partition of n join events by owner rank: d_counts[r] = events owned by r;
+ * d_recs_out / d_payloads_out hold the events grouped by rank in array order inside each
+ * group; d_origin[j] = input index of output event j (to route statuses back).
+ * The exchange itself (all-to-all-v) is the caller's collective. */
+int dj_partition_joins(dj_engine* e, uint32_t n, uint32_t n_ranks,
+                       const dj_join_rec* d_recs, const uint8_t* d_payloads, uint64_t pitch,
+                       dj_join_rec* d_recs_out, uint8_t* d_payloads_out,
+                       uint32_t* d_origin, uint32_t* d_counts);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DJ_ENGINE_H */

@@ -1,0 +1,165 @@
+"""Bit-exact parity of the HIP engine with the CPU oracle on seeded random op-logs.
+
+Each op-log mixes forks (re-forks included), joins with duplicates inside one batch (last
+writer wins, redis.clj:135), joins with max-wait, unknown ids and out-of-range positions,
+sweeps at a moving virtual clock, acks with failures (retry counters, exhaustion), joins
+that land between a sweep and its ack (dirty complete, redis.clj:177-188) and recover
+passes.  Not generated, because the engine documents a different outcome there: a failed
+publish whose metadata snapshot carries another :count than the live barrier.
+"""
+import numpy as np
+import pytest
+
+from tests.parity import ParityDriver, payload_bytes
+
+pytestmark = pytest.mark.gpu
+T0 = 1_700_000_000_000
+
+
+def make_pair(oracle_lib, ids, stride, max_count=999, capacity=None, arena=256 << 20, max_batch=1 << 16, delay=2000):
+    from distributed_join_amd.engine import Engine
+    e = Engine(capacity_barriers=capacity or max(len(ids), 64), arena_bytes=arena, max_count=max_count,
+               payload_stride=stride, max_batch=max_batch, check_publish_delay_ms=delay, host_cap_conts=1 << 16,
+               host_cap_positions=1 << 20)
+    o = oracle_lib.Oracle(ids, max_count=max_count, payload_stride=stride, check_publish_delay_ms=delay)
+    return e, o, ParityDriver(e, o, ids)
+
+
+def run_oplog(d, rng, n_barriers, counts, stride, rounds, batch, hot=None, var_len=False, unknown=0):
+    """counts[b] is fixed per barrier index (a re-fork keeps it)."""
+    now = T0
+    forked = np.zeros(n_barriers, dtype=bool)
+    version = 0
+    inflight = []   # (engine conts, oracle conts) not yet acked
+    for r in range(rounds):
+        now += int(rng.integers(1, 400))
+        # forks: a random subset, some of them re-forks; duplicates inside the batch allowed
+        nf = int(rng.integers(1, max(2, n_barriers // 3)))
+        fb = rng.integers(0, n_barriers, nf)
+        mw = rng.integers(1, 4, nf)
+        d.fork(fb, counts[fb], now + 1000 * mw)
+        forked[fb] = True
+        for _ in range(int(rng.integers(1, 4))):
+            now += int(rng.integers(0, 300))
+            n = int(rng.integers(1, batch))
+            jb = rng.integers(0, n_barriers + unknown, n)
+            if hot is not None:
+                jb[rng.random(n) < 0.3] = hot
+            known = jb < n_barriers
+            cnt = np.where(known, counts[np.minimum(jb, n_barriers - 1)], 4)
+            pos = (rng.random(n) * cnt).astype(np.int64)
+            pos[rng.random(n) < 0.02] += 1000          # out of range
+            version += 1
+            pitch = stride + 16 if var_len else stride
+            pay = payload_bytes(jb, pos % 1024, np.full(n, version) + np.arange(n), pitch)
+            ln = rng.integers(0, stride + 1, n) if var_len else np.full(n, stride)
+            if var_len:
+                ln[rng.random(n) < 0.01] = stride + 5   # too long
+            jmw = np.where(rng.random(n) < 0.2, rng.integers(1, 5, n), 0)
+            d.join(jb, pos, ln, jmw, pay, now)
+            if rng.random() < 0.7:
+                now += int(rng.integers(0, 1500))
+                inflight.append(d.sweep(now))
+            if inflight and rng.random() < 0.6:
+                ec, oc = inflight.pop(0)
+                now += int(rng.integers(0, 50))
+                d.ack(ec, oc, lambda k: (k * 7 + r) % 5 != 0, now)
+        if rng.random() < 0.5:
+            now += int(rng.integers(0, 3000))
+            d.recover(now)
+    while inflight:
+        ec, oc = inflight.pop(0)
+        d.ack(ec, oc, lambda k: True, now)
+    now += 10_000
+    ec, oc = d.sweep(now)
+    d.ack(ec, oc, lambda k: k % 2 == 0, now)
+    d.check_all_snapshots()
+
+
+def test_small_counts_many_duplicates(oracle_lib):
+    rng = np.random.default_rng(1)
+    nb = 40
+    ids = [f"j{b:x}~t{b:x}" for b in range(nb)] + [f"ghost{k}~x" for k in range(5)]
+    counts = rng.integers(1, 9, nb)
+    e, o, d = make_pair(oracle_lib, ids, 64)
+    try:
+        run_oplog(d, rng, nb, counts, 64, rounds=25, batch=400, unknown=5)
+    finally:
+        e.close()
+
+
+def test_hot_barrier_long_chains(oracle_lib):
+    rng = np.random.default_rng(2)
+    nb = 30
+    ids = [f"hot{b}~t{b}" for b in range(nb)]
+    counts = rng.integers(2, 64, nb)
+    counts[3] = 64
+    e, o, d = make_pair(oracle_lib, ids, 64)
+    try:
+        run_oplog(d, rng, nb, counts, 64, rounds=20, batch=3000, hot=3)
+    finally:
+        e.close()
+
+
+def test_large_counts_multiword_bitmaps(oracle_lib):
+    rng = np.random.default_rng(3)
+    nb = 12
+    ids = [f"big{b}~t{b}" for b in range(nb)]
+    counts = np.array([65, 128, 129, 200, 999, 64, 63, 500, 70, 1, 2, 998])
+    e, o, d = make_pair(oracle_lib, ids, 64)
+    try:
+        run_oplog(d, rng, nb, counts, 64, rounds=15, batch=4000, hot=4)
+    finally:
+        e.close()
+
+
+def test_variable_length_messages(oracle_lib):
+    rng = np.random.default_rng(4)
+    nb = 50
+    ids = [f"v{b}~t{b}" for b in range(nb)]
+    counts = rng.integers(1, 20, nb)
+    e, o, d = make_pair(oracle_lib, ids, 256)
+    try:
+        run_oplog(d, rng, nb, counts, 256, rounds=15, batch=500, var_len=True)
+    finally:
+        e.close()
+
+
+def test_kilobyte_messages(oracle_lib):
+    rng = np.random.default_rng(5)
+    nb = 30
+    ids = [f"k{b}~t{b}" for b in range(nb)]
+    counts = rng.integers(1, 17, nb)
+    e, o, d = make_pair(oracle_lib, ids, 1024)
+    try:
+        run_oplog(d, rng, nb, counts, 1024, rounds=10, batch=300, var_len=True)
+    finally:
+        e.close()
+
+
+def test_config2_shape_scaled(oracle_lib):
+    """BASELINE config #2 scaled down: N barriers x count 8, 64-byte messages, uniformly shuffled
+    arrival in 8 batches, one sweep per batch, every ack ok: N complete continuations."""
+    rng = np.random.default_rng(6)
+    nb, c = 20000, 8
+    ids = [f"j{b:x}~t{b:x}" for b in range(nb)]
+    e, o, d = make_pair(oracle_lib, ids, 64, max_count=8, capacity=nb)
+    try:
+        now = T0
+        d.fork(np.arange(nb), np.full(nb, c), np.full(nb, now + 3_600_000))
+        ev = rng.permutation(nb * c)
+        fired = 0
+        for k in range(8):
+            now += 1
+            part = ev[k * nb:(k + 1) * nb]
+            jb, pos = part // c, part % c
+            st = d.join(jb, pos, np.full(nb, 64), np.zeros(nb, np.int64), payload_bytes(jb, pos, np.zeros(nb), 64), now)
+            ec, oc = d.sweep(now)
+            assert all(int(x["flags"]) == 0 for x in ec)
+            assert len(ec) == int((st == 2).sum())
+            fired += len(ec)
+            d.ack(ec, oc, lambda k_: True, now)
+        assert fired == nb
+        assert e.stats()["live"] == 0 and o.live_barriers() == 0
+    finally:
+        e.close()
