@@ -66,6 +66,12 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    # PyTorch ships its own HIP runtime (same soname).  Load it first so that this library
+    # binds to the runtime torch uses: two HIP runtimes in one process do not see the GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, u32, u64, i32 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int
     L.dj_create.restype = i32
