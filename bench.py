@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Throughput bench of the barrier hot path (BASELINE.json metric: join events/sec,
+continuations fired/sec, % of HBM roofline).
+
+Workload (BASELINE.json configs[1], per GPU): 1 M barriers x count 8, 64-byte messages,
+8 M joins in uniformly shuffled order, no timeouts.  One STEP = one batch of 1 M join
+events applied (dj_join_batch), one sweep that pops and gathers every completed barrier
+(dj_sweep) and the ack of all of them (dj_ack_batch); every 8th step starts a new job with
+the fork of its 1 M barriers (dj_fork_batch), inside the timed region.  All inputs are
+resident in HBM before the timed region.
+
+N > 1 (one process per GPU, launched by torch.distributed.run): barriers shard by
+fingerprint, every rank generates a uniform slice of the global event stream, events are
+routed to their owner with an all-to-all over RCCL, then applied locally (weak scaling:
+per-GPU work is fixed).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--barriers", type=int, default=1 << 20, help="barriers per GPU per job")
+    ap.add_argument("--count", type=int, default=8)
+    ap.add_argument("--payload", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    return ap.parse_args()
+
+
+def make_ids(lo, hi):
+    return [f"j{b:x}~t{b:x}" for b in range(lo, hi)]
+
+
+def cpu_baseline(count, payload):
+    """The CPU oracle (a sequential restatement of the reference's core.clj + redis.clj, in-process:
+    no Redis round trips, so an upper bound on the reference) on a bounded sample of the workload."""
+    from oracle import oracle_py
+    nb = 1 << 18
+    ids = make_ids(0, nb)
+    o = oracle_py.Oracle(ids, max_count=count, payload_stride=payload)
+    rng = np.random.default_rng(2)
+    ev = rng.permutation(nb * count)
+    pay = rng.integers(0, 256, (nb, payload), dtype=np.uint8)
+    now = 1_700_000_000_000
+    t = time.perf_counter()
+    o.fork_batch(np.arange(nb), np.full(nb, count), np.full(nb, now + 3_600_000))
+    fired = 0
+    for k in range(count):
+        now += 1
+        part = ev[k * nb:(k + 1) * nb]
+        o.join_batch(part // count, part % count, np.full(nb, payload), np.zeros(nb), pay, now)
+        conts, _, _, _ = o.sweep(now, cap_conts=nb, cap_positions=nb * count)
+        fired += len(conts)
+        o.ack_batch(conts, None, now)
+    dt = time.perf_counter() - t
+    assert fired == nb
+    return {"value": nb * count / dt, "unit": "join events/s", "cores": 1, "kind": "port",
+            "continuations_per_s": nb / dt,
+            "sample": f"{nb} barriers x count {count}, {payload} B messages, {count} batches of {nb} joins, "
+                      "sweep + ack per batch, single thread, in-process (no Redis round trips)"}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    from distributed_join_amd import capi
+    from distributed_join_amd.engine import Engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    nb, c, P = a.barriers, a.count, a.payload
+    batch = nb                      # events per step per GPU
+    steps_per_job = c
+    stride = (P + 63) // 64 * 64
+    pitch = (P + 15) // 16 * 16
+
+    # ---- synthetic job, resident in HBM ------------------------------------------------
+    # global barrier space: world * nb ids; this rank OWNS the ids whose fingerprint maps to it
+    # and GENERATES events for the id range [rank*nb, (rank+1)*nb)
+    ids = make_ids(rank * nb, (rank + 1) * nb)
+    fps = torch.from_numpy(capi.fingerprint_many(ids).view(np.int64)).to(dev)       # (nb, 2)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234 + rank)
+    perm = torch.randperm(nb * c, device=dev, generator=g)
+    b_of, p_of = perm // c, perm % c
+    recs = torch.empty((nb * c, 4), dtype=torch.int64, device=dev)                 # dj_join_rec as 4 x i64
+    recs[:, 0] = fps[b_of, 0]
+    recs[:, 1] = fps[b_of, 1]
+    recs[:, 2] = p_of | (P << 32)          # position | len << 32
+    recs[:, 3] = 0                          # max_wait_s, reserved
+    payloads = torch.randint(0, 256, (nb * c, pitch), dtype=torch.uint8, device=dev, generator=g)
+    fork_recs = torch.empty((nb, 4), dtype=torch.int64, device=dev)                # dj_fork_rec
+    fork_recs[:, 0] = fps[:, 0]
+    fork_recs[:, 1] = fps[:, 1]
+    fork_recs[:, 2] = c
+    fork_recs[:, 3] = 1_700_000_000_000 + 30 * 86_400_000     # deadline far in the future: no timeouts
+    del perm, b_of, p_of
+
+    # ---- engine ------------------------------------------------------------------------------
+    slab_bytes = 64 * (1 + (8 * (1 << (c - 1).bit_length()) + 63) // 64) + (1 << (c - 1).bit_length()) * stride
+    recv_cap = batch if world == 1 else int(batch * 1.25) + 4096
+    eng = Engine(capacity_barriers=int(nb * (1.0 if world == 1 else 1.25)) + 1024,
+                 arena_bytes=int(nb * (1.0 if world == 1 else 1.3) * (slab_bytes + 64)) + (64 << 20), max_count=c,
+                 payload_stride=stride, max_batch=max(recv_cap, nb * 2 if world > 1 else nb), device=local)
+    cap_conts = int(nb * (1.0 if world == 1 else 1.3)) + 1024
+    cap_pos = cap_conts * c
+    d_conts = eng.empty(cap_conts * capi.CONT.itemsize)
+    d_lens = eng.empty(cap_pos * 4)
+    d_pay_out = eng.empty(cap_pos * stride)
+    d_res = eng.empty(16)
+    d_status = eng.empty(max(recv_cap, nb * 2) * 4)
+    d_ack_status = eng.empty(cap_conts * 4)
+    fired_total = torch.zeros(1, dtype=torch.int64, device=dev)
+    es = eng.torch_stream()
+
+    router = None
+    if world > 1:
+        from distributed_join_amd.router import Router
+        router = Router(eng, dist.group.WORLD, max_send=batch, max_recv=max(recv_cap, nb * 2), pitch=pitch)
+
+    now = [1_700_000_000_000]
+
+    def step(k):
+        """One step: (fork at job start) + join batch + sweep + ack."""
+        s = k % steps_per_job
+        now[0] += 1
+        if s == 0:
+            if router is None:
+                eng.fork_batch_dev(nb, fork_recs, d_status)
+            else:
+                r_recs, _, n_in = router.route(fork_recs, None, nb)
+                eng.fork_batch_dev(n_in, r_recs, d_status)
+        lo = s * batch
+        if router is None:
+            eng.join_batch_dev(batch, recs[lo:lo + batch], payloads[lo:lo + batch], pitch, now[0], d_status)
+        else:
+            r_recs, r_pay, n_in = router.route(recs[lo:lo + batch], payloads[lo:lo + batch], batch)
+            eng.join_batch_dev(n_in, r_recs, r_pay, pitch, now[0], d_status)
+        eng.sweep_dev(now[0], cap_conts, cap_pos, d_conts, d_lens, None, d_pay_out, d_res)
+        eng.ack_batch_dev(cap_conts, d_res, d_conts, None, now[0], d_ack_status)
+        with torch.cuda.stream(es):
+            fired_total.add_(d_res[:4].view(torch.int32)[0].to(torch.int64))
+
+    def barrier():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        eng.sync()
+        torch.cuda.synchronize()
+
+    torch.cuda.synchronize()
+    # warmup: whole jobs so the timed region starts at a job boundary with an empty table
+    warm = (a.warmup + steps_per_job - 1) // steps_per_job * steps_per_job if a.warmup else 0
+    for k in range(warm):
+        step(k)
+    barrier()
+    fired_total.zero_()
+    torch.cuda.synchronize()
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record(es)
+    for k in range(a.steps):
+        step(k)
+    ev1.record(es)
+    barrier()
+    wall = time.perf_counter() - t0
+    elapsed = torch.tensor([wall], dtype=torch.float64, device=dev)
+    fired = fired_total.clone()
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        dist.all_reduce(fired)
+    elapsed_s = float(elapsed.item())
+    gpu_ms = ev0.elapsed_time(ev1)
+
+    # ---- per-kernel timing leg (after the timed region): one more job with HIP events around
+    # every kernel on the engine's stream ------------------------------------------------------------
+    kernels = {}
+    roofline = None
+    if not a.no_profile and rank == 0:
+        done = a.steps
+        # finish the job in flight so the profiled job starts on an empty table
+        while done % steps_per_job:
+            step(done)
+            done += 1
+        eng.sync()
+        eng.profile_enable(True)
+        acc = {}
+        for k in range(steps_per_job):
+            step(k)
+            for name, ms in eng.profile_read().items():
+                acc.setdefault(name, []).append(ms)
+        eng.profile_enable(False)
+        fired_job = nb   # per rank at N=1; at N>1 about nb
+        units = {   # algorithmic bytes per launch: per-unit figure x units (kernels table)
+            "join_link": (96, batch), "join_resolve": (16, batch), "join_copy": (2 * P, batch),
+            "join_complex": (0, 0), "pop": (16, eng.stats()["slots"]), "gather": (96 + 2 * c * P, fired_job / steps_per_job),
+            "fork_claim": (96, nb), "fork_apply": (64, nb), "ack": (128, fired_job / steps_per_job)}
+        for name, v in acc.items():
+            avg = sum(v) / len(v)
+            per, n_units = units.get(name, (0, 0))
+            gbps = per * n_units / (avg * 1e-3) / 1e9 if avg > 0 else 0.0
+            kernels[name] = {"avg_ms": round(avg, 4), "launches": len(v), "total_ms": round(sum(v), 4),
+                             "alg_bytes_per_launch": int(per * n_units), "achieved_GBps": round(gbps, 1)}
+        dom = max((k for k in kernels if kernels[k]["alg_bytes_per_launch"] > 0), key=lambda k: kernels[k]["total_ms"])
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            with open(tf) as f:
+                traffic = json.load(f).get(dom)
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": round(kernels[dom]["achieved_GBps"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                    "avg_launch_ms": kernels[dom]["avg_ms"],
+                    "alg_bytes_per_launch": kernels[dom]["alg_bytes_per_launch"]}
+        # the whole join path (link + resolve + copy) against SURVEY's per-event figure 112 + 2P
+        jt = sum(kernels[k]["avg_ms"] for k in ("join_link", "join_resolve", "join_complex", "join_copy") if k in kernels)
+        roofline["join_path"] = {"alg_bytes_per_event": 112 + 2 * P, "ms_per_batch": round(jt, 4),
+                                 "achieved_GBps": round((112 + 2 * P) * batch / (jt * 1e-3) / 1e9, 1),
+                                 "frac": round((112 + 2 * P) * batch / (jt * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(c, P)
+
+    if rank == 0:
+        total_events = a.steps * batch * world
+        out = {
+            "metric": "join events/sec + continuations fired/sec at 1/2/4/8 GPUs; % HBM roofline",
+            "value": total_events / elapsed_s, "unit": "join events/s", "n_gpus": world, "steps": a.steps,
+            "warmup": warm, "ms_per_step": elapsed_s * 1e3 / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64 (integer and byte work)", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {nb} barriers x count {c} per GPU, {P} B messages, uniform arrival, "
+                                   f"no timeouts; step = {batch} joins + sweep/gather + ack, fork of {nb} barriers every "
+                                   f"{steps_per_job} steps", "barriers_per_gpu": nb, "count": c, "payload_bytes": P,
+                       "batch": batch, "sharding": "none" if world == 1 else f"fingerprint hash over {world} GPUs, all-to-all"},
+            "continuations_per_s": float(fired.item()) / elapsed_s,
+            "continuations_fired": int(fired.item()),
+            "gpu_stream_ms": gpu_ms,
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -84,7 +84,7 @@ struct Table {
     unsigned int* ring_head;     // [NUM_CLASSES] pop side
     unsigned int* ring_tail;     // [NUM_CLASSES] push side
     unsigned int* ring_tail_snap;// [NUM_CLASSES] tail at the start of the current call: pops stop here
-    unsigned long long* stat;    // [0] live slots, [1] tombstones, [2] free units in rings
+    unsigned long long* stat;    // scratch of stats_kernel: [0] live slots, [1] tombstones
     uint32_t stride;
     uint32_t max_count;
     uint32_t max_retry_publish, max_retry_timeout_publish;
@@ -185,8 +185,6 @@ __device__ inline int64_t find_or_claim(const Table& t, uint64_t lo, uint64_t hi
             if (a_cas(&tl->fp_lo, expect, lo)) {
                 a_store(&tl->fp_hi, hi);
                 *created = true;
-                a_add(&t.stat[0], 1ull);
-                if (tomb >= 0) a_add(&t.stat[1], ~0ull);
                 return (int64_t)target;
             }
             restart = true;  // somebody else claimed it: probe again from the home slot
@@ -197,38 +195,88 @@ __device__ inline int64_t find_or_claim(const Table& t, uint64_t lo, uint64_t hi
 }
 
 // ---- slab allocation ---------------------------------------------------------------
-__device__ inline uint32_t slab_alloc(const Table& t, uint32_t k) {
-    // freed slabs first, bounded by the tail snapshot so a pop never reads an entry that a
-    // concurrent push has not written yet
-    // (head and tail are free-running 32-bit counters, ring_cap is a power of two)
-    unsigned int snap = t.ring_tail_snap[k];
-    if ((int)(snap - a_load(&t.ring_head[k])) > 0) {
-        unsigned int h = a_add(&t.ring_head[k], 1u);
-        if ((int)(snap - h) > 0) {
-            a_add(&t.stat[2], ~(unsigned long long)slab_units(k, t.stride) + 1ull);
-            return t.ring[k][h & (t.ring_cap[k] - 1)];
-        }
-        a_add(&t.ring_head[k], ~0u);
+// All three helpers are WAVE-COOPERATIVE: every lane of the wave must call them in converged
+// control flow (lanes with nothing to do pass want/has = false).  A single hot word sustains
+// only ~90 atomics per microsecond on this chip, so the wave issues one atomic per distinct
+// size class (rings) or one per wave (bump pointer), never one per lane.
+
+// in-wave inclusive prefix sum
+__device__ inline uint32_t wave_incl_scan(uint32_t v) {
+    const uint32_t lane = lane_id();
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t o = __shfl_up(v, off);
+        if ((int)lane >= off) v += o;
     }
-    uint32_t units = slab_units(k, t.stride);
-    unsigned long long u = a_add(t.bump, (unsigned long long)units);
-    if (u + units > t.arena_units) {
-        a_add(t.bump, ~(unsigned long long)units + 1ull);
-        return 0;
-    }
-    return (uint32_t)u;
-}
-__device__ inline void slab_free(const Table& t, uint32_t k, uint32_t slab) {
-    if (slab == 0) return;
-    unsigned int tl = a_add(&t.ring_tail[k], 1u);
-    t.ring[k][tl & (t.ring_cap[k] - 1)] = slab;
-    a_add(&t.stat[2], (unsigned long long)slab_units(k, t.stride));
+    return v;
 }
 
-// redis/complete's deletions (redis.clj:180-185) for a slot this thread owns
-__device__ inline void delete_slot(const Table& t, uint64_t s) {
+// Returns a slab of class k for lanes with want, or 0 when the arena is exhausted.
+// Freed slabs first (ring pops are bounded by the tail snapshot taken at the start of the
+// call, so a pop never reads an entry that a push of the same launch has not written yet;
+// head and tail are free-running 32-bit counters, ring_cap is a power of two).
+__device__ inline uint32_t wave_slab_alloc(const Table& t, bool want, uint32_t k) {
+    const uint32_t lane = lane_id();
+    uint32_t slab = 0;
+    uint64_t todo = __ballot(want);
+    while (todo) {
+        const int l0 = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t k0 = __shfl(k, l0);
+        const uint64_t grp = __ballot(want && k == k0);
+        const uint32_t m = (uint32_t)__popcll(grp);
+        const uint32_t rank = (uint32_t)__popcll(grp & ((1ull << lane) - 1));
+        uint32_t h = 0;
+        int got = 0;
+        if ((int)lane == l0) {
+            const unsigned int snap = t.ring_tail_snap[k0];
+            if ((int)(snap - a_load(&t.ring_head[k0])) > 0) {
+                h = a_add(&t.ring_head[k0], m);
+                const int avail = (int)(snap - h);
+                got = avail < 0 ? 0 : (avail > (int)m ? (int)m : avail);
+                if (got < (int)m) a_add(&t.ring_head[k0], (unsigned int)(got - (int)m));   // give back the overshoot
+            }
+        }
+        h = __shfl(h, l0);
+        got = __shfl(got, l0);
+        if (want && k == k0 && (int)rank < got) slab = t.ring[k0][(h + rank) & (t.ring_cap[k0] - 1)];
+        todo &= ~grp;
+    }
+    const bool need = want && slab == 0;
+    const uint32_t units = need ? slab_units(k, t.stride) : 0;
+    const uint32_t incl = wave_incl_scan(units);
+    const uint32_t total = __shfl(incl, 63);
+    if (total == 0) return slab;
+    unsigned long long base = 0;
+    if (lane == 0) base = a_add(t.bump, (unsigned long long)total);
+    base = __shfl(base, 0);
+    if (need) {
+        const unsigned long long u = base + incl - units;
+        if (u + units <= t.arena_units) slab = (uint32_t)u;
+    }
+    return slab;
+}
+
+// Returns the slabs of lanes with has (class k) to the free rings.
+__device__ inline void wave_slab_free(const Table& t, bool has, uint32_t k, uint32_t slab) {
+    const uint32_t lane = lane_id();
+    has = has && slab != 0;
+    uint64_t todo = __ballot(has);
+    while (todo) {
+        const int l0 = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t k0 = __shfl(k, l0);
+        const uint64_t grp = __ballot(has && k == k0);
+        const uint32_t rank = (uint32_t)__popcll(grp & ((1ull << lane) - 1));
+        unsigned int tl = 0;
+        if ((int)lane == l0) tl = a_add(&t.ring_tail[k0], (unsigned int)__popcll(grp));
+        tl = __shfl(tl, l0);
+        if (has && k == k0) t.ring[k0][(tl + rank) & (t.ring_cap[k0] - 1)] = slab;
+        todo &= ~grp;
+    }
+}
+
+// redis/complete's deletions (redis.clj:180-185) for a slot this thread owns.  The slab goes
+// back through wave_slab_free by the caller.
+__device__ inline void clear_slot(const Table& t, uint64_t s) {
     Slot* sl = &t.slots[s];
-    if (sl->slab) slab_free(t, class_of(sl->count), sl->slab);
     sl->count = 0;
     sl->meta = 0;
     sl->slab = 0;
@@ -241,8 +289,6 @@ __device__ inline void delete_slot(const Table& t, uint64_t s) {
     sl->fp_lo = FP_TOMB;
     t.q_primary[s] = NQ;
     t.q_backup[s] = NQ;
-    a_add(&t.stat[0], ~0ull);
-    a_add(&t.stat[1], 1ull);
 }
 
 __device__ inline uint64_t* slab_bitmap(const Table& t, uint32_t slab) {

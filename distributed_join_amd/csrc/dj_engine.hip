@@ -32,7 +32,22 @@ struct dj_engine {
     void* allocs[64];
     int n_allocs;
     std::string err;
+    // optional per-kernel timing (dj_profile_enable): one event pair per kernel id
+    int profiling;
+    hipEvent_t ev_start[DJ_PROF_KERNELS], ev_stop[DJ_PROF_KERNELS];
+    int ev_used[DJ_PROF_KERNELS];
 };
+
+// Launch `call` on the engine's stream; with profiling on, bracket it with the kernel id's events.
+#define LAUNCH(e, kid, call)                                                   \
+    do {                                                                       \
+        if ((e)->profiling) (void)hipEventRecord((e)->ev_start[kid], (e)->stream); \
+        call;                                                                  \
+        if ((e)->profiling) {                                                  \
+            (void)hipEventRecord((e)->ev_stop[kid], (e)->stream);              \
+            (e)->ev_used[kid] = 1;                                             \
+        }                                                                      \
+    } while (0)
 
 static std::string g_create_err;
 
@@ -120,6 +135,10 @@ extern "C" void dj_destroy(dj_engine* e) {
     if (e->stream) {
         (void)hipStreamSynchronize(e->stream);
         (void)hipStreamDestroy(e->stream);
+    }
+    for (int k = 0; k < DJ_PROF_KERNELS; ++k) {
+        if (e->ev_start[k]) (void)hipEventDestroy(e->ev_start[k]);
+        if (e->ev_stop[k]) (void)hipEventDestroy(e->ev_stop[k]);
     }
     for (int i = 0; i < e->n_allocs; ++i) (void)hipFree(e->allocs[i]);
     delete e;
@@ -210,6 +229,8 @@ extern "C" int dj_create(const dj_config* cfg, dj_engine** out) {
     e->cfg = *cfg;
     e->n_allocs = 0;
     e->stream = nullptr;
+    e->profiling = 0;
+    for (int k = 0; k < DJ_PROF_KERNELS; ++k) { e->ev_start[k] = nullptr; e->ev_stop[k] = nullptr; e->ev_used[k] = 0; }
     int rc = create_impl(e);
     if (rc != DJ_OK) {
         g_create_err = e->err;
@@ -229,6 +250,31 @@ extern "C" int dj_sync(dj_engine* e) {
 
 extern "C" void* dj_stream(dj_engine* e) { return e ? (void*)e->stream : nullptr; }
 
+extern "C" int dj_profile_enable(dj_engine* e, int on) {
+    if (!e) return DJ_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    if (on)
+        for (int k = 0; k < DJ_PROF_KERNELS; ++k) {
+            if (!e->ev_start[k]) HIP_TRY(e, hipEventCreate(&e->ev_start[k]));
+            if (!e->ev_stop[k]) HIP_TRY(e, hipEventCreate(&e->ev_stop[k]));
+        }
+    for (int k = 0; k < DJ_PROF_KERNELS; ++k) e->ev_used[k] = 0;
+    e->profiling = on ? 1 : 0;
+    return DJ_OK;
+}
+
+extern "C" int dj_profile_read(dj_engine* e, float* h_ms) {
+    if (!e || !h_ms) return DJ_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    for (int k = 0; k < DJ_PROF_KERNELS; ++k) {
+        h_ms[k] = -1.0f;
+        if (e->ev_used[k]) HIP_TRY(e, hipEventElapsedTime(&h_ms[k], e->ev_start[k], e->ev_stop[k]));
+        e->ev_used[k] = 0;
+    }
+    return DJ_OK;
+}
+
 // ---- hot path ----------------------------------------------------------------------------
 extern "C" int dj_fork_batch(dj_engine* e, uint32_t n, const dj_fork_rec* d_recs, int32_t* d_status) {
     if (!e) return DJ_E_INVALID;
@@ -237,8 +283,8 @@ extern "C" int dj_fork_batch(dj_engine* e, uint32_t n, const dj_fork_rec* d_recs
     if (n > e->cfg.max_batch) return fail(e, DJ_E_TOO_LARGE, "fork: n=%u exceeds max_batch=%u", n, e->cfg.max_batch);
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     snapshot_tails_kernel<<<1, 64, 0, e->stream>>>(e->t);
-    fork_claim_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, d_recs, n, d_status);
-    fork_apply_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, d_recs, n, d_status);
+    LAUNCH(e, DJ_PROF_FORK_CLAIM, (fork_claim_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, d_recs, n, d_status)));
+    LAUNCH(e, DJ_PROF_FORK_APPLY, (fork_apply_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, d_recs, n, d_status)));
     HIP_TRY(e, hipGetLastError());
     return DJ_OK;
 }
@@ -262,15 +308,15 @@ extern "C" int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs
     if (n > e->cfg.max_batch) return fail(e, DJ_E_TOO_LARGE, "join: n=%u exceeds max_batch=%u", n, e->cfg.max_batch);
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     HIP_TRY(e, hipMemsetAsync(e->w.counters, 0, C_COUNT * 4, e->stream));
-    join_link_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, d_recs, n, pitch, d_status);
-    join_resolve_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, now_ms, d_status);
-    join_resolve_complex_kernel<<<256, 64, 0, e->stream>>>(e->t, e->w, now_ms, d_status);
+    LAUNCH(e, DJ_PROF_JOIN_LINK, (join_link_kernel<<<grid_for(n, LINK_BLOCK), LINK_BLOCK, 0, e->stream>>>(e->t, e->w, d_recs, n, pitch, d_status)));
+    LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, now_ms, d_status)));
+    LAUNCH(e, DJ_PROF_JOIN_COMPLEX, (join_resolve_complex_kernel<<<256, 64, 0, e->stream>>>(e->t, e->w, now_ms, d_status)));
     const uint32_t lanes = e->cfg.payload_stride / 16;
-    if (lanes <= 4) launch_join_copy<4>(e, n, d_recs, d_payloads, pitch);
-    else if (lanes <= 8) launch_join_copy<8>(e, n, d_recs, d_payloads, pitch);
-    else if (lanes <= 16) launch_join_copy<16>(e, n, d_recs, d_payloads, pitch);
-    else if (lanes <= 32) launch_join_copy<32>(e, n, d_recs, d_payloads, pitch);
-    else launch_join_copy<64>(e, n, d_recs, d_payloads, pitch);
+    if (lanes <= 4) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<4>(e, n, d_recs, d_payloads, pitch));
+    else if (lanes <= 8) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<8>(e, n, d_recs, d_payloads, pitch));
+    else if (lanes <= 16) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<16>(e, n, d_recs, d_payloads, pitch));
+    else if (lanes <= 32) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<32>(e, n, d_recs, d_payloads, pitch));
+    else LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<64>(e, n, d_recs, d_payloads, pitch));
     HIP_TRY(e, hipGetLastError());
     return DJ_OK;
 }
@@ -279,6 +325,12 @@ static uint32_t scan_blocks(const dj_engine* e) {
     uint64_t b = (e->t.mask + 1) / 256;
     if (b > 4096) b = 4096;
     if (b < 1) b = 1;
+    return (uint32_t)b;
+}
+
+static uint32_t pop_blocks(const dj_engine* e) {
+    uint64_t b = (e->t.mask + 1 + 256 * POP_ITEMS - 1) / (256 * POP_ITEMS);
+    if (b > 2048) b = 2048;
     return (uint32_t)b;
 }
 
@@ -296,12 +348,12 @@ static int sweep_impl(dj_engine* e, const char* what, uint64_t now_ms, uint32_t 
     dj_sweep_result* res = d_result ? d_result : e->d_result;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     HIP_TRY(e, hipMemsetAsync(res, 0, sizeof(dj_sweep_result), e->stream));
-    pop_due_kernel<<<scan_blocks(e), 256, 0, e->stream>>>(e->t, e->w, now_ms, cap_conts, cap_positions, gather, d_conts, res);
+    LAUNCH(e, DJ_PROF_POP, (pop_due_kernel<<<pop_blocks(e), 256, 0, e->stream>>>(e->t, e->w, now_ms, cap_conts, cap_positions, gather, d_conts, res)));
     finish_result_kernel<<<1, 64, 0, e->stream>>>(res, cap_conts, cap_positions, gather);
     if (gather) {
         uint32_t blocks = grid_for((uint64_t)cap_conts * 64, 256);
         if (blocks > 16384) blocks = 16384;
-        gather_kernel<<<blocks, 256, 0, e->stream>>>(e->t, e->w, d_conts, res, 0, 1, d_lens, d_max_waits, d_payloads);
+        LAUNCH(e, DJ_PROF_GATHER, (gather_kernel<<<blocks, 256, 0, e->stream>>>(e->t, e->w, d_conts, res, 0, 1, d_lens, d_max_waits, d_payloads)));
     }
     HIP_TRY(e, hipGetLastError());
     if (h_result) {
@@ -331,7 +383,7 @@ extern "C" int dj_ack_batch(dj_engine* e, uint32_t n, const uint32_t* d_n, const
     if (!d_conts || !d_status) return fail(e, DJ_E_INVALID, "ack: null pointer");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     snapshot_tails_kernel<<<1, 64, 0, e->stream>>>(e->t);
-    ack_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, n, d_n, d_conts, d_ok, now_ms, d_status);
+    LAUNCH(e, DJ_PROF_ACK, (ack_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, n, d_n, d_conts, d_ok, now_ms, d_status)));
     HIP_TRY(e, hipGetLastError());
     return DJ_OK;
 }
@@ -345,7 +397,7 @@ extern "C" int dj_recover(dj_engine* e, uint64_t now_ms, uint32_t cap, dj_cont* 
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     HIP_TRY(e, hipMemsetAsync(res, 0, sizeof(dj_sweep_result), e->stream));
     snapshot_tails_kernel<<<1, 64, 0, e->stream>>>(e->t);
-    recover_kernel<<<scan_blocks(e), 256, 0, e->stream>>>(e->t, now_ms, cap, d_conts, d_status, res);
+    LAUNCH(e, DJ_PROF_RECOVER, (recover_kernel<<<scan_blocks(e), 256, 0, e->stream>>>(e->t, now_ms, cap, d_conts, d_status, res)));
     finish_result_kernel<<<1, 64, 0, e->stream>>>(res, cap, 0, 0);
     HIP_TRY(e, hipGetLastError());
     if (h_result) {
@@ -407,14 +459,22 @@ extern "C" int dj_get_stats(dj_engine* e, dj_stats* h_stats) {
     if (!e || !h_stats) return DJ_E_INVALID;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     unsigned long long st[4], bump;
+    unsigned int head[NUM_CLASSES], tail[NUM_CLASSES];
+    HIP_TRY(e, hipMemsetAsync(e->t.stat, 0, 4 * 8, e->stream));
+    stats_kernel<<<scan_blocks(e), 256, 0, e->stream>>>(e->t);
+    HIP_TRY(e, hipGetLastError());
     HIP_TRY(e, hipMemcpyAsync(st, e->t.stat, sizeof st, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipMemcpyAsync(&bump, e->t.bump, 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(head, e->t.ring_head, sizeof head, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(tail, e->t.ring_tail, sizeof tail, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     h_stats->slots = e->t.mask + 1;
     h_stats->live = st[0];
     h_stats->tombstones = st[1];
     h_stats->arena_units_used = bump;
-    h_stats->arena_units_free = st[2];
+    h_stats->arena_units_free = 0;
+    for (uint32_t k = 0; k < NUM_CLASSES; ++k)
+        h_stats->arena_units_free += (uint64_t)(tail[k] - head[k]) * slab_units(k, e->t.stride);
     return DJ_OK;
 }
 

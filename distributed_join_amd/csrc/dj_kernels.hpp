@@ -39,25 +39,38 @@ __global__ void __launch_bounds__(256) fork_claim_kernel(Table t, Work w, const 
 // pass 2: the winning record of each slot resets the barrier.
 __global__ void __launch_bounds__(256) fork_apply_kernel(Table t, Work w, const dj_fork_rec* recs, uint32_t n,
                                                          int32_t* status) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t s = w.slot_of[i];
-    if (s == 0xFFFFFFFFu) return;
-    Slot* sl = &t.slots[s];
-    if (sl->chain != i + 1) return;  // an equal barrier-id later in the batch supersedes this record
-    const dj_fork_rec r = recs[i];
-    const uint32_t k_new = class_of(r.count);
-    uint32_t slab = sl->slab;
-    if (slab == 0 || class_of(sl->count) != k_new) {
-        uint32_t fresh = slab_alloc(t, k_new);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // phase A (per lane): is this record the winner of its slot, and does the slot need a new slab
+    bool active = false, need = false;
+    uint32_t s = 0xFFFFFFFFu, k_new = 0, k_old = 0, old_slab = 0;
+    dj_fork_rec r = {};
+    Slot* sl = nullptr;
+    if (i < n) s = w.slot_of[i];
+    if (s != 0xFFFFFFFFu) {
+        sl = &t.slots[s];
+        active = sl->chain == i + 1;   // an equal barrier-id later in the batch supersedes this record
+    }
+    if (active) {
+        r = recs[i];
+        k_new = class_of(r.count);
+        old_slab = sl->slab;
+        k_old = class_of(sl->count);
+        need = old_slab == 0 || k_old != k_new;
+    }
+    // phase B (wave-cooperative): one atomic per size class / per wave
+    const uint32_t fresh = wave_slab_alloc(t, need, k_new);
+    wave_slab_free(t, need && fresh != 0, k_old, old_slab);
+    if (!active) return;
+    // phase C (per lane)
+    uint32_t slab = old_slab;
+    if (need) {
         if (fresh == 0) {
             // engine limit, no counterpart in the reference: report it and leave the table as it was
             status[i] = DJ_FORK_NO_SPACE;
             sl->chain = 0;
-            if (!(sl->meta & META_HAS) && t.q_primary[s] == NQ && t.q_backup[s] == NQ) delete_slot(t, s);
+            if (!(sl->meta & META_HAS) && t.q_primary[s] == NQ && t.q_backup[s] == NQ) clear_slot(t, s);
             return;
         }
-        if (slab) slab_free(t, class_of(sl->count), slab);
         slab = fresh;
     }
     if (r.count > 64) {
@@ -86,8 +99,30 @@ __global__ void __launch_bounds__(256) fork_apply_kernel(Table t, Work w, const 
 // position, the HSET semantics of redis.clj:135).
 // =====================================================================================
 
-__global__ void __launch_bounds__(256) join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n,
-                                                        uint64_t pitch, int32_t* status) {
+// Append one element per thread with pred set, ONE atomic per block (a hot counter word
+// sustains only ~90 atomics per microsecond).  Every thread of the block must call it.
+// lds: 17 words of shared memory.  Returns the index, 0xFFFFFFFF without pred.
+__device__ inline uint32_t block_append(unsigned int* counter, bool pred, uint32_t* lds) {
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint64_t m = __ballot(pred);
+    if (lane == 0) lds[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (uint32_t v = 0; v < nw; ++v) { const uint32_t c = lds[v]; lds[v] = tot; tot += c; }
+        lds[16] = tot ? a_add(counter, tot) : 0u;
+    }
+    __syncthreads();
+    const uint32_t r = lds[16] + lds[wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+    __syncthreads();
+    return pred ? r : 0xFFFFFFFFu;
+}
+
+constexpr int LINK_BLOCK = 1024;
+
+__global__ void __launch_bounds__(LINK_BLOCK) join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n,
+                                                               uint64_t pitch, int32_t* status) {
+    __shared__ uint32_t lds[17];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool first = false;
     uint32_t slot = 0;
@@ -103,9 +138,9 @@ __global__ void __launch_bounds__(256) join_link_kernel(Table t, Work w, const d
             if (s < 0 || !(t.slots[s].meta & META_HAS) || t.slots[s].slab == 0) st = DJ_JOIN_NOT_FOUND;   // redis.clj:152
             else if (b.x >= t.slots[s].count) st = DJ_JOIN_BAD_POSITION;          // redis.clj:153
         }
-        w.dst[i] = NODST;
         if (st != 0) {
             status[i] = st;
+            w.dst[i] = NODST;      // accepted events get their dst from the resolve pass
         } else {
             uint32_t prev = a_xchg(&t.slots[s].chain, i + 1);
             w.node[i] = node_pack(prev, b.x, b.z);
@@ -113,7 +148,7 @@ __global__ void __launch_bounds__(256) join_link_kernel(Table t, Work w, const d
             slot = (uint32_t)s;
         }
     }
-    uint32_t at = wave_append(&w.counters[C_TOUCHED], first);
+    uint32_t at = block_append(&w.counters[C_TOUCHED], first, lds);
     if (first) w.touched[at] = slot;
 }
 
@@ -203,7 +238,7 @@ __global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint
 #pragma unroll
                     for (int j = k + 1; j < CHAIN_REG; ++j)
                         if (j < m && node_pos(nd[j]) == pos) last = false;
-                    if (last) w.dst[idx[k]] = d;
+                    w.dst[idx[k]] = last ? d : NODST;
                 }
             }
             sl->bits = count > 64 ? (uint64_t)r.arrived : r.bits;
@@ -293,7 +328,7 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
                     if (mw) { uint64_t at = now + 1000ull * mw; if (at < at_min) at_min = at; }
                 }
                 status[i] = st;
-                if (fmax[pos] == i + 1) w.dst[i] = d;
+                w.dst[i] = fmax[pos] == i + 1 ? d : NODST;
                 cur = node_next(x);
             }
             sl->bits = count > 64 ? (uint64_t)arrived : bits0;
@@ -358,57 +393,69 @@ __device__ inline void fill_cont(dj_cont* c, const Slot& sl, uint64_t now, uint6
 }
 
 // One pass over q_primary: every slot with score <= now is popped (ZRANGEBYSCORE +
-// ZREMRANGEBYSCORE 0 now).  Output indices come from one atomic pair per wave (ballot +
-// in-wave prefix sum).  res->n_conts / n_positions are the raw cursors until
-// finish_result_kernel clamps them.
+// ZREMRANGEBYSCORE 0 now).  A block scans chunks of 256 * POP_ITEMS slots; output indices for a
+// chunk come from a block-wide prefix sum and ONE atomic pair per chunk.  res->n_conts /
+// n_positions are the raw cursors until finish_result_kernel clamps them.
+constexpr int POP_ITEMS = 8;
+
 __global__ void __launch_bounds__(256) pop_due_kernel(Table t, Work w, uint64_t now, uint32_t cap_conts,
                                                       uint64_t cap_pos, int alloc_pos, dj_cont* conts,
                                                       dj_sweep_result* res) {
+    __shared__ uint32_t wave_c[4], wave_p[4];
+    __shared__ uint32_t base_c_s;
+    __shared__ unsigned long long base_p_s;
     const uint64_t nslots = t.mask + 1;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint32_t lane = threadIdx.x & 63;
-    // all lanes of a wave iterate together (nslots is a multiple of 64)
-    for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < nslots; s += stride) {
-        const uint64_t pa = t.q_primary[s];
-        const bool due = pa <= now;
-        const uint64_t m = __ballot(due);
-        if (m == 0) continue;
-        uint32_t cnt = 0;
-        Slot sl;
-        if (due) {
-            sl = t.slots[s];
-            cnt = (sl.meta & META_HAS) ? sl.count : 0;
+    const uint64_t chunk = 256ull * POP_ITEMS;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (uint64_t cb = blockIdx.x * chunk; cb < nslots; cb += (uint64_t)gridDim.x * chunk) {
+        uint32_t nd = 0, ps = 0, due_mask = 0;
+        uint32_t cnts[POP_ITEMS];
+#pragma unroll
+        for (int j = 0; j < POP_ITEMS; ++j) {
+            const uint64_t s = cb + (uint64_t)j * 256 + tid;
+            cnts[j] = 0;
+            if (s < nslots && t.q_primary[s] <= now) {
+                const uint2 cm = *reinterpret_cast<const uint2*>(&t.slots[s].count);   // count, meta
+                cnts[j] = (cm.y & META_HAS) ? cm.x : 0;
+                due_mask |= 1u << j;
+                ++nd;
+                ps += cnts[j];
+            }
         }
-        // in-wave exclusive prefix sum of the position counts
-        uint32_t incl = cnt;
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t v = __shfl_up(incl, off);
-            if ((int)lane >= off) incl += v;
+        const uint32_t incl_c = wave_incl_scan(nd), incl_p = wave_incl_scan(ps);
+        if (lane == 63) { wave_c[wv] = incl_c; wave_p[wv] = incl_p; }
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t tc = wave_c[0] + wave_c[1] + wave_c[2] + wave_c[3];
+            const uint32_t tp = wave_p[0] + wave_p[1] + wave_p[2] + wave_p[3];
+            base_c_s = tc ? a_add(&res->n_conts, tc) : 0u;
+            base_p_s = (alloc_pos && tp) ? a_add((unsigned long long*)&res->n_positions, (unsigned long long)tp) : 0ull;
         }
-        const uint32_t total_pos = __shfl(incl, 63);
-        const int leader = __ffsll((unsigned long long)m) - 1;
-        uint32_t base_c = 0;
-        unsigned long long base_p = 0;
-        if ((int)lane == leader) {
-            base_c = a_add(&res->n_conts, (uint32_t)__popcll(m));
-            if (alloc_pos) base_p = a_add((unsigned long long*)&res->n_positions, (unsigned long long)total_pos);
+        __syncthreads();
+        uint32_t my_c = base_c_s + incl_c - nd;
+        uint64_t my_p = base_p_s + incl_p - ps;
+        for (uint32_t v = 0; v < wv; ++v) { my_c += wave_c[v]; my_p += wave_p[v]; }
+#pragma unroll
+        for (int j = 0; j < POP_ITEMS; ++j) {
+            if (!(due_mask & (1u << j))) continue;
+            const uint64_t s = cb + (uint64_t)j * 256 + tid;
+            const uint32_t c_idx = my_c++;
+            const uint64_t p_idx = my_p;
+            my_p += cnts[j];
+            if (c_idx >= cap_conts) { res->more = 1; continue; }
+            if (alloc_pos && p_idx + cnts[j] > cap_pos) {
+                res->more = 1;
+                conts[c_idx].flags = CONT_VOID;      // index taken, barrier stays queued
+                conts[c_idx].count = 0;
+                w.cont_slot[c_idx] = 0xFFFFFFFFu;
+                continue;
+            }
+            const uint64_t pa = t.q_primary[s];
+            t.q_primary[s] = NQ;                    // popped; the backup entry stays (redis.clj:288)
+            fill_cont(&conts[c_idx], t.slots[s], now, pa, p_idx);
+            w.cont_slot[c_idx] = (uint32_t)s;
         }
-        base_c = __shfl(base_c, leader);
-        base_p = __shfl(base_p, leader);
-        if (!due) continue;
-        const uint32_t my_c = base_c + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-        const uint64_t my_p = base_p + (incl - cnt);
-        if (my_c >= cap_conts) { res->more = 1; continue; }
-        if (alloc_pos && my_p + cnt > cap_pos) {
-            res->more = 1;
-            conts[my_c].flags = CONT_VOID;      // index taken, barrier stays queued
-            conts[my_c].count = 0;
-            w.cont_slot[my_c] = 0xFFFFFFFFu;
-            continue;
-        }
-        t.q_primary[s] = NQ;                    // popped; the backup entry stays (redis.clj:288)
-        fill_cont(&conts[my_c], sl, now, pa, my_p);
-        w.cont_slot[my_c] = (uint32_t)s;
+        __syncthreads();
     }
 }
 
@@ -469,13 +516,11 @@ __global__ void __launch_bounds__(256) gather_kernel(Table t, Work w, const dj_c
 // =====================================================================================
 
 // core/complete on a slot this thread owns: redis/complete (Lua, redis.clj:177-188) and on
-// "Join Updated" reset-publish.  Returns true when the barrier was deleted.
-__device__ inline bool complete_slot(const Table& t, uint64_t s, uint64_t now) {
+// "Join Updated" reset-publish.  Returns true when the barrier is to be deleted; the caller
+// then frees the slab (wave-cooperatively) and clears the slot.
+__device__ inline bool complete_decide(const Table& t, uint64_t s, uint64_t now) {
     Slot* sl = &t.slots[s];
-    if (sl->join_ts == sl->join_ts_read) {          // two nils compare equal
-        delete_slot(t, s);
-        return true;
-    }
+    if (sl->join_ts == sl->join_ts_read) return true;          // two nils compare equal
     // reset-publish: both retry counters dropped, :publish-retry-cnt 0, re-queued at now
     sl->meta = meta_pack(sl->meta & META_HAS, 0, RETRY_NIL);
     t.q_backup[s] = now;
@@ -483,81 +528,112 @@ __device__ inline bool complete_slot(const Table& t, uint64_t s, uint64_t now) {
     return false;
 }
 
-// retry bookkeeping shared by the publish-failure path (snapshot metadata) and the recover
-// path (fresh metadata): returns the DJ_ACK_* outcome.
-__device__ inline int32_t retry_or_drop(const Table& t, uint64_t s, uint64_t deadline, uint32_t rp, uint32_t rt,
-                                        uint64_t now) {
-    const bool timeout = now > deadline;                                  // core.clj:137
-    const uint32_t cur = timeout ? rt : rp;
-    const uint32_t cnt = cur == RETRY_NIL ? 0 : cur;                      // core.clj:139
-    const uint32_t max = timeout ? t.max_retry_timeout_publish : t.max_retry_publish;
-    if (cnt >= max)                                                       // core.clj:142-147
-        return complete_slot(t, s, now) ? DJ_ACK_DROPPED_EXHAUSTED : DJ_ACK_REQUEUED_DIRTY;
-    Slot* sl = &t.slots[s];
-    if (timeout) rt = cnt + 1; else rp = cnt + 1;                         // core.clj:151
-    sl->meta = meta_pack(true, rp, rt);
+// attempt-retry-publish's counter selection (core.clj:137-141): which counter, its value, its cap
+__device__ inline bool retries_left(const Table& t, uint64_t deadline, uint32_t rp, uint32_t rt, uint64_t now,
+                                    bool* timeout, uint32_t* cnt) {
+    *timeout = now > deadline;                                            // core.clj:137
+    const uint32_t cur = *timeout ? rt : rp;
+    *cnt = cur == RETRY_NIL ? 0 : cur;                                    // core.clj:139
+    return *cnt < (*timeout ? t.max_retry_timeout_publish : t.max_retry_publish);   // core.clj:142
+}
+
+// update-to-retry-publish (core.clj:107-111): counter + 1, re-queued at now
+__device__ inline void retry_requeue(const Table& t, uint64_t s, bool timeout, uint32_t cnt, uint32_t rp, uint32_t rt,
+                                     uint64_t now) {
+    if (timeout) rt = cnt + 1; else rp = cnt + 1;
+    t.slots[s].meta = meta_pack(true, rp, rt);
     t.q_backup[s] = now;
     t.q_primary[s] = now;
-    return DJ_ACK_RETRY;
 }
 
 __global__ void __launch_bounds__(256) ack_kernel(Table t, uint32_t n_max, const uint32_t* d_n, const dj_cont* conts,
                                                   const uint8_t* ok, uint64_t now, int32_t* status) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t n = d_n ? (*d_n < n_max ? *d_n : n_max) : n_max;
-    if (i >= n) return;
-    const dj_cont c = conts[i];
-    if (c.flags & CONT_VOID) { status[i] = 0; return; }
-    const bool published = ok == nullptr || ok[i] != 0;
-    const bool has_md = !(c.flags & DJ_CONT_NO_METADATA);
-    if (!has_md || published) {
-        // core.clj:159-161 / 134-136 (no metadata) or core.clj:168 (published): complete
-        int64_t s = find_slot(t, c.fp_lo, c.fp_hi);
-        bool deleted = s < 0 ? true : complete_slot(t, (uint64_t)s, now);
-        status[i] = !deleted ? DJ_ACK_REQUEUED_DIRTY : (has_md ? DJ_ACK_DONE : DJ_ACK_DONE_NO_METADATA);
-        return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = d_n ? (*d_n < n_max ? *d_n : n_max) : n_max;
+    // ---- phase A (per lane): decide -----------------------------------------------------------
+    int32_t st = 0;
+    bool clear = false, free_old = false, alloc = false, write_back = false, timeout = false;
+    uint64_t s_u = 0;
+    uint32_t k_old = 0, old_slab = 0, k_new = 0, cnt = 0, rp = RETRY_NIL, rt = RETRY_NIL;
+    dj_cont c = {};
+    const bool live = i < n;
+    if (live) c = conts[i];
+    if (live && !(c.flags & CONT_VOID)) {
+        const bool published = ok == nullptr || ok[i] != 0;
+        const bool has_md = !(c.flags & DJ_CONT_NO_METADATA);
+        rp = retry_from_api(c.retry_publish);
+        rt = retry_from_api(c.retry_timeout);
+        bool complete_path = !has_md || published;     // core.clj:159-161 / 134-136 (no metadata), core.clj:168 (published)
+        int32_t deleted_code = has_md ? DJ_ACK_DONE : DJ_ACK_DONE_NO_METADATA;
+        if (!complete_path && !retries_left(t, c.deadline_ms, rp, rt, now, &timeout, &cnt)) {
+            complete_path = true;                      // core.clj:142-147: retries exhausted
+            deleted_code = DJ_ACK_DROPPED_EXHAUSTED;
+        }
+        if (complete_path) {
+            const int64_t s = find_slot(t, c.fp_lo, c.fp_hi);
+            if (s < 0) {
+                st = deleted_code;                     // nothing left to delete
+            } else if (complete_decide(t, (uint64_t)s, now)) {
+                st = deleted_code;
+                clear = true;
+                s_u = (uint64_t)s;
+                old_slab = t.slots[s].slab;
+                k_old = class_of(t.slots[s].count);
+                free_old = old_slab != 0;
+            } else {
+                st = DJ_ACK_REQUEUED_DIRTY;
+            }
+        } else {
+            // publish failed, retries left: update-metadata writes the publisher's snapshot back
+            // (redis.clj:106-111), creating the key if the barrier was deleted meanwhile
+            bool created;
+            const int64_t s = find_or_claim(t, c.fp_lo, c.fp_hi, &created);
+            if (s >= 0) {
+                s_u = (uint64_t)s;
+                Slot* sl = &t.slots[s];
+                if (created) {
+                    sl->count = 0; sl->meta = 0; sl->slab = 0; sl->chain = 0;
+                    sl->deadline = 0; sl->join_ts = 0; sl->join_ts_read = 0; sl->bits = 0;
+                    t.q_primary[s] = NQ; t.q_backup[s] = NQ;
+                }
+                write_back = true;
+                k_new = class_of(c.count);
+                if (sl->count != c.count) {
+                    // the snapshot's :count differs from the live one (barrier re-forked or deleted while
+                    // its publish was in flight): positions at or beyond the new count are dropped
+                    if (sl->slab == 0 || class_of(sl->count) != k_new) {
+                        old_slab = sl->slab;
+                        k_old = class_of(sl->count);
+                        free_old = old_slab != 0;
+                        alloc = true;
+                    } else if (c.count <= 64) {
+                        sl->bits &= c.count == 64 ? ~0ull : ((1ull << c.count) - 1);
+                    }
+                }
+            }
+        }
     }
-    // publish failed: attempt-retry-publish with the metadata the publisher holds (the snapshot)
-    const uint32_t rp = retry_from_api(c.retry_publish), rt = retry_from_api(c.retry_timeout);
-    const bool timeout = now > c.deadline_ms;
-    const uint32_t cur = timeout ? rt : rp;
-    const uint32_t cnt = cur == RETRY_NIL ? 0 : cur;
-    const uint32_t max = timeout ? t.max_retry_timeout_publish : t.max_retry_publish;
-    if (cnt >= max) {
-        int64_t s = find_slot(t, c.fp_lo, c.fp_hi);
-        bool deleted = s < 0 ? true : complete_slot(t, (uint64_t)s, now);
-        status[i] = deleted ? DJ_ACK_DROPPED_EXHAUSTED : DJ_ACK_REQUEUED_DIRTY;
-        return;
-    }
-    // update-metadata writes the snapshot back (redis.clj:106-111), creating the key if the
-    // barrier was deleted meanwhile, then store-in-publish-queue at now (core.clj:110-111)
-    bool created;
-    int64_t s = find_or_claim(t, c.fp_lo, c.fp_hi, &created);
-    if (s < 0) { status[i] = 0; return; }
-    Slot* sl = &t.slots[s];
-    if (created) {
-        sl->count = 0; sl->meta = 0; sl->slab = 0; sl->chain = 0;
-        sl->deadline = 0; sl->join_ts = 0; sl->join_ts_read = 0; sl->bits = 0;
-    }
-    if (sl->count != c.count) {
-        // the snapshot's :count differs from the live one (barrier re-forked or deleted while its
-        // publish was in flight): positions at or beyond the new count are dropped
-        const uint32_t k_new = class_of(c.count);
-        if (sl->slab == 0 || class_of(sl->count) != k_new) {
-            if (sl->slab) slab_free(t, class_of(sl->count), sl->slab);
-            sl->slab = slab_alloc(t, k_new);
+    // ---- phase B (wave-cooperative): slab traffic, one atomic per size class -------------------
+    wave_slab_free(t, free_old, k_old, old_slab);
+    const uint32_t fresh = wave_slab_alloc(t, alloc, k_new);
+    // ---- phase C (per lane): finish ------------------------------------------------------------------
+    if (clear) clear_slot(t, s_u);
+    if (write_back) {
+        Slot* sl = &t.slots[s_u];
+        if (alloc) {
+            sl->slab = fresh;
             sl->bits = 0;
-            if (c.count > 64 && sl->slab) {
-                uint64_t* bm = slab_bitmap(t, sl->slab);
+            if (c.count > 64 && fresh) {
+                uint64_t* bm = slab_bitmap(t, fresh);
                 for (uint32_t j = 0; j < (class_positions(k_new) >> 6); ++j) bm[j] = 0;
             }
-        } else if (c.count <= 64) {
-            sl->bits &= c.count == 64 ? ~0ull : ((1ull << c.count) - 1);
         }
         sl->count = c.count;
+        sl->deadline = c.deadline_ms;
+        retry_requeue(t, s_u, timeout, cnt, rp, rt, now);                  // core.clj:151
+        st = DJ_ACK_RETRY;
     }
-    sl->deadline = c.deadline_ms;
-    status[i] = retry_or_drop(t, (uint64_t)s, c.deadline_ms, rp, rt, now);
+    if (live) status[i] = st;
 }
 
 // core/recover-unprocessed-publish-messages: ZRANGEBYSCORE backup 0 (now - delay), then the
@@ -567,24 +643,69 @@ __global__ void __launch_bounds__(256) recover_kernel(Table t, uint64_t now, uin
     const uint64_t nslots = t.mask + 1;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t max_score = now - t.check_publish_delay_ms;
+    // all lanes of a wave iterate together (nslots is a multiple of the grid's wave size)
     for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < nslots; s += stride) {
         const uint64_t ba = t.q_backup[s];
         const bool due = ba <= max_score;
+        if (__ballot(due) == 0) continue;
         const uint32_t at = wave_append(&res->n_conts, due);
-        if (!due) continue;
-        Slot sl = t.slots[s];
-        int32_t st;
-        if (!(sl.meta & META_HAS)) {
-            st = complete_slot(t, s, now) ? DJ_ACK_DONE_NO_METADATA : DJ_ACK_REQUEUED_DIRTY;   // core.clj:134-136
-        } else {
-            st = retry_or_drop(t, s, sl.deadline, meta_retry_pub(sl.meta), meta_retry_to(sl.meta), now);
+        int32_t st = 0;
+        bool clear = false;
+        uint32_t k_old = 0, old_slab = 0;
+        Slot sl = {};
+        if (due) {
+            sl = t.slots[s];
+            bool timeout = false, drop;
+            uint32_t cnt = 0;
+            int32_t deleted_code;
+            if (!(sl.meta & META_HAS)) {                                   // core.clj:134-136
+                drop = true;
+                deleted_code = DJ_ACK_DONE_NO_METADATA;
+            } else {
+                drop = !retries_left(t, sl.deadline, meta_retry_pub(sl.meta), meta_retry_to(sl.meta), now, &timeout, &cnt);
+                deleted_code = DJ_ACK_DROPPED_EXHAUSTED;
+            }
+            if (!drop) {
+                retry_requeue(t, s, timeout, cnt, meta_retry_pub(sl.meta), meta_retry_to(sl.meta), now);
+                st = DJ_ACK_RETRY;
+            } else if (complete_decide(t, s, now)) {
+                st = deleted_code;
+                clear = true;
+                old_slab = sl.slab;
+                k_old = class_of(sl.count);
+            } else {
+                st = DJ_ACK_REQUEUED_DIRTY;
+            }
         }
-        if (at < cap) {
-            fill_cont(&conts[at], sl, now, ba, 0);
-            status[at] = st;
-        } else {
-            res->more = 1;
+        wave_slab_free(t, clear && old_slab != 0, k_old, old_slab);
+        if (clear) clear_slot(t, s);
+        if (due) {
+            if (at < cap) {
+                fill_cont(&conts[at], sl, now, ba, 0);
+                status[at] = st;
+            } else {
+                res->more = 1;
+            }
         }
+    }
+}
+
+// live slots and tombstones, counted on demand (dj_get_stats)
+__global__ void __launch_bounds__(256) stats_kernel(Table t) {
+    const uint64_t nslots = t.mask + 1;
+    unsigned long long live = 0, tomb = 0;
+    for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = t.slots[s].fp_lo;
+        live += k >= 2;
+        tomb += k == FP_TOMB;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        live += __shfl_xor(live, off);
+        tomb += __shfl_xor(tomb, off);
+    }
+    if (lane_id() == 0) {
+        if (live) a_add(&t.stat[0], live);
+        if (tomb) a_add(&t.stat[1], tomb);
     }
 }
 

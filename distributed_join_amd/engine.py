@@ -231,6 +231,15 @@ class Engine:
         self._check(self.L.dj_queue_scores(self.h, int(fp_lo), int(fp_hi), ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
+    def profile_enable(self, on=True):
+        self._check(self.L.dj_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self):
+        """-> {kernel name: ms of its most recent launch} for kernels launched since the last read."""
+        ms = np.zeros(len(capi.PROF_KERNELS), dtype=np.float32)
+        self._check(self.L.dj_profile_read(self.h, ms.ctypes.data_as(ctypes.c_void_p)))
+        return {k: float(v) for k, v in zip(capi.PROF_KERNELS, ms) if v >= 0}
+
     def stats(self):
         st = np.zeros(1, dtype=STATS)
         self._check(self.L.dj_get_stats(self.h, st.ctypes.data_as(ctypes.c_void_p)))

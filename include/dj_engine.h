@@ -224,6 +224,19 @@ typedef struct dj_stats {
 } dj_stats;
 int dj_get_stats(dj_engine* e, dj_stats* h_stats);
 
+/* ---- per-kernel timing (measurement aid; no counterpart in the reference) ---------- */
+/* Kernel ids for dj_profile_read.  With profiling enabled every launch of these kernels is
+ * bracketed by a pair of HIP events on the engine's stream. */
+enum {
+    DJ_PROF_FORK_CLAIM = 0, DJ_PROF_FORK_APPLY, DJ_PROF_JOIN_LINK, DJ_PROF_JOIN_RESOLVE,
+    DJ_PROF_JOIN_COMPLEX, DJ_PROF_JOIN_COPY, DJ_PROF_POP, DJ_PROF_GATHER, DJ_PROF_ACK,
+    DJ_PROF_RECOVER, DJ_PROF_KERNELS
+};
+int dj_profile_enable(dj_engine* e, int on);
+/* Waits for the stream; h_ms[DJ_PROF_KERNELS] = duration in ms of the most recent launch of
+ * each kernel since the previous read, or -1 when it was not launched. */
+int dj_profile_read(dj_engine* e, float* h_ms);
+
 /* ---- multi-GPU routing helper (device pointers) ---------------------------------- */
 
 /* owner rank of a barrier among n_ranks engines */
