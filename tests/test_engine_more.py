@@ -1,0 +1,206 @@
+"""More GPU checks through the C ABI: output caps of the sweep, the routing partition kernel,
+BASELINE config #3's shape (Zipf counts, 30 % expire through the timeout sweep) against the
+oracle, and config #2 at full size through size-independent properties."""
+import numpy as np
+import pytest
+
+from distributed_join_amd import capi
+from tests.parity import ParityDriver, payload_bytes
+
+pytestmark = pytest.mark.gpu
+T0 = 1_700_000_000_000
+
+
+def _engine(**kw):
+    from distributed_join_amd.engine import Engine
+    return Engine(**kw)
+
+
+def test_sweep_caps_leave_the_rest_queued(oracle_lib):
+    """A sweep pops only what fits the caller's buffers and reports `more`; repeating it drains the
+    queue, and the union equals the oracle's single pop."""
+    nb = 300
+    ids = [f"cap{b}~t" for b in range(nb)]
+    counts = np.array([1 + b % 6 for b in range(nb)])
+    e = _engine(capacity_barriers=nb, arena_bytes=32 << 20, max_count=8, payload_stride=64, max_batch=4096,
+                host_cap_conts=64, host_cap_positions=100)
+    o = oracle_lib.Oracle(ids, max_count=8, payload_stride=64)
+    d = ParityDriver(e, o, ids)
+    try:
+        d.fork(np.arange(nb), counts, np.full(nb, T0 + 1000))
+        jb = np.arange(nb)
+        d.join(jb, np.zeros(nb, np.int64), np.full(nb, 64), np.zeros(nb, np.int64), payload_bytes(jb, jb * 0, jb * 0, 64), T0 + 5)
+        oc, ol, om, op_ = o.sweep(T0 + 2000)             # everything timed out
+        want = d._canon_oracle(oc, ol, om, op_)
+        got, rounds = {}, 0
+        while True:
+            conts, lens, mws, pay, more = e.sweep(T0 + 2000)
+            assert len(conts) <= 64 and len(lens) <= 100
+            part = d._canon_engine(conts, lens, mws, pay)
+            assert not (got.keys() & part.keys())
+            got.update(part)
+            rounds += 1
+            if not more:
+                break
+            assert rounds < 100
+        assert rounds > 1
+        assert got == want
+        assert all(v[0][2] == capi.DJ_CONT_TIMEOUT for v in got.values())
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("n_ranks", [1, 2, 3, 8])
+def test_partition_kernel_is_a_stable_partition_by_owner(n_ranks):
+    import torch
+    from distributed_join_amd.router import owner_of_np
+    n, pitch = 100_003, 48
+    rng = np.random.default_rng(n_ranks)
+    e = _engine(capacity_barriers=64, arena_bytes=1 << 20, max_count=8, payload_stride=64, max_batch=1 << 17)
+    try:
+        recs = np.zeros(n, dtype=capi.JOIN_REC)
+        recs["fp_lo"] = rng.integers(2, 1 << 62, n, dtype=np.uint64)
+        recs["fp_hi"] = rng.integers(1, 1 << 62, n, dtype=np.uint64)
+        recs["position"] = np.arange(n) % 1000
+        recs["len"] = 48
+        pay = rng.integers(0, 256, (n, pitch), dtype=np.uint8)
+        dev = e.device
+        d_recs = torch.from_numpy(recs.view(np.uint8).reshape(-1).copy()).to(dev)
+        d_pay = torch.from_numpy(pay).to(dev)
+        d_ro, d_po = torch.empty_like(d_recs), torch.empty_like(d_pay)
+        d_origin = torch.empty(n, dtype=torch.int32, device=dev)
+        d_counts = torch.zeros(64, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        e.partition_joins_dev(n, n_ranks, d_recs, d_pay, pitch, d_ro, d_po, d_origin, d_counts)
+        e.sync()
+        owners = owner_of_np(recs["fp_hi"], n_ranks)
+        assert all(capi.owner_of(int(r["fp_lo"]), int(r["fp_hi"]), n_ranks) == int(w) for r, w in zip(recs[:200], owners[:200]))
+        order = np.argsort(owners, kind="stable")
+        np.testing.assert_array_equal(d_counts.cpu().numpy()[:n_ranks], np.bincount(owners, minlength=n_ranks))
+        np.testing.assert_array_equal(d_origin.cpu().numpy(), order.astype(np.int32))
+        assert bytes(d_ro.cpu().numpy()) == recs[order].tobytes()
+        np.testing.assert_array_equal(d_po.cpu().numpy(), pay[order])
+    finally:
+        e.close()
+
+
+def zipf_counts(rng, n, lo=2, hi=64):
+    k = np.arange(lo, hi + 1)
+    p = 1.0 / k
+    return rng.choice(k, size=n, p=p / p.sum())
+
+
+def test_config3_shape_scaled(oracle_lib):
+    """BASELINE config #3 scaled: counts Zipf(1) over [2, 64], 30 % of the barriers get a strict
+    subset of their positions and a deadline inside the run; the clock advances 1 ms per batch.
+    Expect 70 % COMPLETE + 30 % TIMEOUT continuations with exact presence, bit-exact with the oracle."""
+    rng = np.random.default_rng(3)
+    nb = 6000
+    ids = [f"j{b:x}~t{b:x}" for b in range(nb)]
+    counts = zipf_counts(rng, nb)
+    expire = rng.random(nb) < 0.3
+    e = _engine(capacity_barriers=nb, arena_bytes=256 << 20, max_count=64, payload_stride=64, max_batch=1 << 17,
+                host_cap_conts=1 << 14, host_cap_positions=1 << 19)
+    o = oracle_lib.Oracle(ids, max_count=64, payload_stride=64)
+    d = ParityDriver(e, o, ids)
+    try:
+        ev_b, ev_p = [], []
+        for b in range(nb):
+            pos = np.arange(counts[b])
+            if expire[b]:
+                pos = rng.permutation(pos)[:rng.integers(0, counts[b])]      # strict subset, maybe empty
+            ev_b.append(np.full(len(pos), b))
+            ev_p.append(pos)
+        ev_b, ev_p = np.concatenate(ev_b), np.concatenate(ev_p)
+        perm = rng.permutation(len(ev_b))
+        ev_b, ev_p = ev_b[perm], ev_p[perm]
+        batches = 20
+        now = T0
+        # deadlines fall on odd milliseconds inside the run, sweeps on even ones: a barrier popped at
+        # now == deadline would NOT be a timeout (is-timeout? is strict, core.clj:86-89)
+        deadline = np.where(expire, T0 + 11 + 2 * rng.integers(0, batches, nb), T0 + 3_600_000)
+        d.fork(np.arange(nb), counts, deadline)
+        n_complete = n_timeout = 0
+        per = (len(ev_b) + batches - 1) // batches
+        for k in range(batches + 15):
+            now += 2
+            sl = slice(k * per, (k + 1) * per)
+            if len(ev_b[sl]):
+                jb, jp = ev_b[sl], ev_p[sl]
+                d.join(jb, jp, np.full(len(jb), 64), np.zeros(len(jb), np.int64), payload_bytes(jb, jp, jb * 0, 64), now)
+            ec, oc = d.sweep(now)
+            for c in ec:
+                if int(c["flags"]) & capi.DJ_CONT_TIMEOUT:
+                    n_timeout += 1
+                else:
+                    n_complete += 1
+            d.ack(ec, oc, lambda k_: True, now)
+        assert n_complete == int((~expire).sum())
+        assert n_timeout == int(expire.sum())
+        assert e.stats()["live"] == 0 and o.live_barriers() == 0
+    finally:
+        e.close()
+
+
+def test_config2_full_size_properties():
+    """BASELINE config #2 at full size (1 M barriers x count 8, 64 B messages, 8 M joins, batches of
+    1 M): every barrier fires exactly once, COMPLETE, with every byte where the generator put it."""
+    import torch
+    nb, c, P = 1 << 20, 8, 64
+    rng = np.random.default_rng(22)
+    ids = [f"j{b:x}~t{b:x}" for b in range(nb)]
+    fps = capi.fingerprint_many(ids)
+    e = _engine(capacity_barriers=nb, arena_bytes=nb * 640 + (64 << 20), max_count=c, payload_stride=P, max_batch=nb)
+    dev = e.device
+    try:
+        frecs = np.zeros(nb, dtype=capi.FORK_REC)
+        frecs["fp_lo"], frecs["fp_hi"], frecs["count"], frecs["deadline_ms"] = fps[:, 0], fps[:, 1], c, T0 + 3_600_000
+        st = e.fork_batch(frecs)
+        assert (st == capi.DJ_FORK_CREATED).all()
+        ev = rng.permutation(nb * c)
+        cap_c, cap_p = nb, nb * c
+        d_conts, d_lens, d_pay, d_res = e.empty(cap_c * 64), e.empty(cap_p * 4), e.empty(cap_p * P), e.empty(16)
+        d_ack = e.empty(cap_c * 4)
+        fired = np.zeros(nb, dtype=np.int32)
+        lookup = {}
+        order = np.lexsort((fps[:, 1], fps[:, 0]))
+        sorted_lo, sorted_hi = fps[order, 0], fps[order, 1]
+        total_complete = 0
+        for k in range(c):
+            now = T0 + 1 + k
+            part = ev[k * nb:(k + 1) * nb]
+            jb, jp = part // c, part % c
+            recs = np.zeros(nb, dtype=capi.JOIN_REC)
+            recs["fp_lo"], recs["fp_hi"], recs["position"], recs["len"] = fps[jb, 0], fps[jb, 1], jp, P
+            st = e.join_batch(recs, payload_bytes(jb, jp, jb * 0, P), now)
+            assert np.isin(st, [capi.DJ_JOIN_WAITING, capi.DJ_JOIN_COMPLETE]).all()
+            total_complete += int((st == capi.DJ_JOIN_COMPLETE).sum())
+            res = np.zeros(1, dtype=capi.SWEEP_RESULT)
+            e.sweep_dev(now, cap_c, cap_p, d_conts, d_lens, None, d_pay, d_res, res)
+            n, npos = int(res[0]["n_conts"]), int(res[0]["n_positions"])
+            assert not res[0]["more"] and npos == n * c
+            conts = d_conts[:n * 64].cpu().numpy().view(capi.CONT)
+            assert (conts["flags"] == 0).all() and (conts["count"] == c).all()
+            # which barrier is each continuation: binary search on the sorted fingerprints
+            at = np.searchsorted(sorted_lo, conts["fp_lo"])
+            assert (sorted_lo[at] == conts["fp_lo"]).all() and (sorted_hi[at] == conts["fp_hi"]).all()
+            bidx = order[at]
+            np.add.at(fired, bidx, 1)
+            lens = d_lens[:npos * 4].cpu().numpy().view(np.uint32)
+            assert (lens == P).all()
+            got = d_pay[:npos * P].cpu().numpy().reshape(n, c, P)
+            pb = (conts["pos_base"]).astype(np.int64)
+            assert sorted(pb.tolist()) == list(range(0, npos, c))
+            got = d_pay[:npos * P].cpu().numpy().reshape(npos, P)
+            rows = (pb[:, None] + np.arange(c)[None, :]).reshape(-1)
+            want = payload_bytes(np.repeat(bidx, c), np.tile(np.arange(c), n), np.zeros(n * c), P)
+            assert np.array_equal(got[rows], want), "a gathered byte differs from the generator"
+            e.ack_batch_dev(n, None, d_conts, None, now, d_ack)
+            e.sync()
+            assert (d_ack[:n * 4].cpu().numpy().view(np.int32) == capi.DJ_ACK_DONE).all()
+        assert (fired == 1).all()
+        assert total_complete == nb
+        s = e.stats()
+        assert s["live"] == 0 and s["tombstones"] == nb
+    finally:
+        e.close()
