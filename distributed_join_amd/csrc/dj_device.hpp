@@ -5,9 +5,16 @@
 //                One record = one Redis key family of the reference:
 //                "<id>:metadata", "<id>:join-ts", "<id>:join-ts-read" and the presence set of
 //                the hash "<id>" (reference redis.clj:42-73).
-//   q_primary[]  score of the slot's barrier in "publish-queue"        (redis.clj:36), or NQ
-//   q_backup[]   score in "publish-queue-backup"                       (redis.clj:37), or NQ
-//                Two flat u64 arrays so the sweeps stream 8 bytes per slot.
+//   q[]          one u64 per slot for BOTH sorted sets "publish-queue" / "publish-queue-backup"
+//                (redis.clj:36-37).  Every writer of the reference keeps a member's two scores
+//                equal (store-in-publish-queue redis.clj:257-258, store-nearest redis.clj:270-271)
+//                and the only asymmetric operation removes it from the primary set
+//                (all-publish-messages, redis.clj:288), so a member is in one of three states:
+//                  in both, same score : q = score
+//                  backup only         : q = score | Q_POPPED
+//                  in neither          : q = Q_NONE
+//                `q <= now` is then exactly "in the primary set with score <= now": the sweep
+//                streams 8 bytes per slot and every queue update touches one line.
 //   arena        payload slabs in 64-byte units, one slab per barrier, size class = count
 //                rounded up to a power of two:
 //                  [bitmap words, only when class > 64 positions]
@@ -25,6 +32,8 @@ namespace dj {
 constexpr uint64_t FP_EMPTY = 0;       // never-used slot (fp_lo)
 constexpr uint64_t FP_TOMB = 1;        // deleted slot (fp_lo), fp_hi = 0
 constexpr uint64_t NQ = DJ_NOT_QUEUED;
+constexpr uint64_t Q_NONE = ~0ull;          // in neither queue
+constexpr uint64_t Q_POPPED = 1ull << 63;   // removed from the primary queue, still in the backup queue
 constexpr uint32_t META_HAS = 1u;      // metadata key exists
 constexpr uint32_t RETRY_NIL = 0xFFu;  // retry counter absent
 constexpr int NUM_CLASSES = 11;        // 1, 2, 4 ... 1024 positions
@@ -44,6 +53,8 @@ struct __attribute__((aligned(64))) Slot {
 };
 static_assert(sizeof(Slot) == 64, "slot must be one 64-byte line");
 
+__host__ __device__ inline uint64_t q_primary_at(uint64_t v) { return (v >> 63) ? NQ : v; }
+__host__ __device__ inline uint64_t q_backup_at(uint64_t v) { return v == Q_NONE ? NQ : (v & ~Q_POPPED); }
 __host__ __device__ inline uint32_t meta_pack(bool has, uint32_t rp, uint32_t rt) {
     return (has ? META_HAS : 0u) | ((rp & 0xFFu) << 8) | ((rt & 0xFFu) << 16);
 }
@@ -73,8 +84,7 @@ __host__ __device__ inline uint32_t slab_units(uint32_t k, uint32_t stride) {
 
 struct Table {
     Slot* slots;
-    uint64_t* q_primary;
-    uint64_t* q_backup;
+    uint64_t* q;                 // queue word per slot, see the layout note above
     uint64_t mask;               // slots - 1
     uint8_t* arena;
     uint64_t arena_units;
@@ -99,9 +109,17 @@ struct Work {
     uint32_t* complex_;  // slots whose chain is too long for the register path
     uint32_t* slot_of;   // fork: slot of record i
     uint32_t* cont_slot; // sweep: slot of continuation k
-    unsigned int* counters;  // C_* below
+    unsigned int* counters;       // C_* below, bank of the current join batch
+    unsigned int* counters_next;  // the other bank: zeroed by the current batch for the next one
+    unsigned long long* sweep;    // S_* below, bank of the current sweep
+    unsigned long long* sweep_next;
 };
-enum { C_TOUCHED = 0, C_COMPLEX = 1, C_ERROR = 2, C_COUNT = 8 };
+enum { C_TOUCHED = 0, C_COMPLEX = 1, C_COUNT = 8 };
+// sweep scratch: S_CURSOR packs both output cursors so a block takes its output range with one
+// atomic: continuations in the low 31 bits, positions above (positions * 64 B <= arena <= 256 GiB)
+enum { S_CURSOR = 0, S_MORE = 1, S_COUNT = 2 };
+constexpr int CURSOR_SHIFT = 31;
+constexpr unsigned long long CURSOR_CONT_MASK = (1ull << CURSOR_SHIFT) - 1;
 
 // ---- atomics (agent scope, relaxed) ------------------------------------------------
 template <class T>
@@ -255,6 +273,58 @@ __device__ inline uint32_t wave_slab_alloc(const Table& t, bool want, uint32_t k
     return slab;
 }
 
+// Block-cooperative form for kernels where (almost) every thread allocates the same class:
+// ONE ring pop and ONE bump add per block for the block's first class; threads of other
+// classes go through the wave path.  Every thread of the block must call it.
+// lds: 24 words of shared memory.
+__device__ inline uint32_t block_slab_alloc(const Table& t, bool want, uint32_t k, uint32_t* lds) {
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (threadIdx.x == 0) lds[16] = 0xFFFFFFFFu;
+    __syncthreads();
+    if (want) atomicMin(&lds[16], k);
+    __syncthreads();
+    const uint32_t kb = lds[16];
+    if (kb == 0xFFFFFFFFu) return 0;                       // nobody allocates (uniform across the block)
+    const bool fast = want && k == kb;
+    const uint64_t m = __ballot(fast);
+    if (lane == 0) lds[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (uint32_t v = 0; v < nw; ++v) { const uint32_t c = lds[v]; lds[v] = tot; tot += c; }
+        uint32_t h = 0;
+        int got = 0;
+        const unsigned int snap = t.ring_tail_snap[kb];
+        h = a_add(&t.ring_head[kb], tot);
+        const int avail = (int)(snap - h);
+        got = avail < 0 ? 0 : (avail > (int)tot ? (int)tot : avail);
+        if (got < (int)tot) a_add(&t.ring_head[kb], (unsigned int)(got - (int)tot));    // give back the overshoot
+        unsigned long long base = 0;
+        const uint32_t rest = tot - (uint32_t)got;
+        if (rest) base = a_add(t.bump, (unsigned long long)rest * slab_units(kb, t.stride));
+        lds[17] = h;
+        lds[18] = (uint32_t)got;
+        lds[19] = (uint32_t)base;
+        lds[20] = (uint32_t)(base >> 32);
+    }
+    __syncthreads();
+    uint32_t slab = 0;
+    if (fast) {
+        const uint32_t rank = lds[wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        const uint32_t h = lds[17], got = lds[18];
+        if (rank < got) {
+            slab = t.ring[kb][(h + rank) & (t.ring_cap[kb] - 1)];
+        } else {
+            const uint32_t units = slab_units(kb, t.stride);
+            const unsigned long long u = (((unsigned long long)lds[20] << 32) | lds[19]) + (unsigned long long)(rank - got) * units;
+            if (u + units <= t.arena_units) slab = (uint32_t)u;
+        }
+    }
+    __syncthreads();
+    const uint32_t other = wave_slab_alloc(t, want && !fast, k);
+    return fast ? slab : other;
+}
+
 // Returns the slabs of lanes with has (class k) to the free rings.
 __device__ inline void wave_slab_free(const Table& t, bool has, uint32_t k, uint32_t slab) {
     const uint32_t lane = lane_id();
@@ -287,8 +357,7 @@ __device__ inline void clear_slot(const Table& t, uint64_t s) {
     sl->bits = 0;
     sl->fp_hi = 0;
     sl->fp_lo = FP_TOMB;
-    t.q_primary[s] = NQ;
-    t.q_backup[s] = NQ;
+    t.q[s] = Q_NONE;
 }
 
 __device__ inline uint64_t* slab_bitmap(const Table& t, uint32_t slab) {

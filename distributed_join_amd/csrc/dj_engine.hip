@@ -33,6 +33,9 @@ struct dj_engine {
     int n_allocs;
     std::string err;
     // optional per-kernel timing (dj_profile_enable): one event pair per kernel id
+    int ctr_bank, sweep_bank;    // which half of the double-banked scratch the next call uses
+    unsigned int* d_counters;    // 2 x C_COUNT
+    unsigned long long* d_sweep; // 2 x S_COUNT
     int profiling;
     hipEvent_t ev_start[DJ_PROF_KERNELS], ev_stop[DJ_PROF_KERNELS];
     int ev_used[DJ_PROF_KERNELS];
@@ -162,8 +165,7 @@ static int create_impl(dj_engine* e) {
     t.arena_units = c.arena_bytes / 64;
     if (t.arena_units >= (1ull << 32)) return fail(e, DJ_E_INVALID, "arena_bytes too large (max 256 GiB)");
     ALLOC(e, t.slots, slots * sizeof(Slot));
-    ALLOC(e, t.q_primary, slots * 8);
-    ALLOC(e, t.q_backup, slots * 8);
+    ALLOC(e, t.q, slots * 8);
     ALLOC(e, t.arena, t.arena_units * 64);
     ALLOC(e, t.bump, 8);
     ALLOC(e, t.ring_head, NUM_CLASSES * 4);
@@ -180,8 +182,7 @@ static int create_impl(dj_engine* e) {
         ALLOC(e, t.ring[k], cap * 4);
     }
     HIP_TRY(e, hipMemsetAsync(t.slots, 0, slots * sizeof(Slot), e->stream));
-    HIP_TRY(e, hipMemsetAsync(t.q_primary, 0xFF, slots * 8, e->stream));
-    HIP_TRY(e, hipMemsetAsync(t.q_backup, 0xFF, slots * 8, e->stream));
+    HIP_TRY(e, hipMemsetAsync(t.q, 0xFF, slots * 8, e->stream));
     const unsigned long long one = 1;   // arena unit 0 is reserved: slab 0 means "no slab"
     HIP_TRY(e, hipMemcpyAsync(t.bump, &one, 8, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(e, hipMemsetAsync(t.ring_head, 0, NUM_CLASSES * 4, e->stream));
@@ -197,8 +198,15 @@ static int create_impl(dj_engine* e) {
     ALLOC(e, w.complex_, nb * 4);
     ALLOC(e, w.slot_of, nb * 4);
     ALLOC(e, w.cont_slot, (nb > slots ? nb : slots) * 4);
-    ALLOC(e, w.counters, C_COUNT * 4);
-    HIP_TRY(e, hipMemsetAsync(w.counters, 0, C_COUNT * 4, e->stream));
+    ALLOC(e, e->d_counters, 2 * C_COUNT * 4);
+    HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 2 * C_COUNT * 4, e->stream));
+    ALLOC(e, e->d_sweep, 2 * S_COUNT * 8);
+    HIP_TRY(e, hipMemsetAsync(e->d_sweep, 0, 2 * S_COUNT * 8, e->stream));
+    e->ctr_bank = e->sweep_bank = 0;
+    w.counters = e->d_counters;
+    w.counters_next = e->d_counters + C_COUNT;
+    w.sweep = e->d_sweep;
+    w.sweep_next = e->d_sweep + S_COUNT;
 
     ALLOC(e, e->d_one_cont, sizeof(dj_cont));
     ALLOC(e, e->d_one_scores, 16);
@@ -282,9 +290,8 @@ extern "C" int dj_fork_batch(dj_engine* e, uint32_t n, const dj_fork_rec* d_recs
     if (!d_recs || !d_status || !aligned16(d_recs)) return fail(e, DJ_E_INVALID, "fork: null or misaligned pointer");
     if (n > e->cfg.max_batch) return fail(e, DJ_E_TOO_LARGE, "fork: n=%u exceeds max_batch=%u", n, e->cfg.max_batch);
     HIP_TRY(e, hipSetDevice(e->cfg.device));
-    snapshot_tails_kernel<<<1, 64, 0, e->stream>>>(e->t);
     LAUNCH(e, DJ_PROF_FORK_CLAIM, (fork_claim_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, d_recs, n, d_status)));
-    LAUNCH(e, DJ_PROF_FORK_APPLY, (fork_apply_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, d_recs, n, d_status)));
+    LAUNCH(e, DJ_PROF_FORK_APPLY, (fork_apply_kernel<<<grid_for(n, FORK_APPLY_BLOCK), FORK_APPLY_BLOCK, 0, e->stream>>>(e->t, e->w, d_recs, n, d_status)));
     HIP_TRY(e, hipGetLastError());
     return DJ_OK;
 }
@@ -307,7 +314,10 @@ extern "C" int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs
         return fail(e, DJ_E_INVALID, "join: records and payloads must be 16-byte aligned, pitch a positive multiple of 16");
     if (n > e->cfg.max_batch) return fail(e, DJ_E_TOO_LARGE, "join: n=%u exceeds max_batch=%u", n, e->cfg.max_batch);
     HIP_TRY(e, hipSetDevice(e->cfg.device));
-    HIP_TRY(e, hipMemsetAsync(e->w.counters, 0, C_COUNT * 4, e->stream));
+    // double-banked counters: this batch counts in one bank and zeroes the other for the next batch
+    e->w.counters = e->d_counters + e->ctr_bank * C_COUNT;
+    e->w.counters_next = e->d_counters + (e->ctr_bank ^ 1) * C_COUNT;
+    e->ctr_bank ^= 1;
     LAUNCH(e, DJ_PROF_JOIN_LINK, (join_link_kernel<<<grid_for(n, LINK_BLOCK), LINK_BLOCK, 0, e->stream>>>(e->t, e->w, d_recs, n, pitch, d_status)));
     LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, now_ms, d_status)));
     LAUNCH(e, DJ_PROF_JOIN_COMPLEX, (join_resolve_complex_kernel<<<256, 64, 0, e->stream>>>(e->t, e->w, now_ms, d_status)));
@@ -334,6 +344,28 @@ static uint32_t pop_blocks(const dj_engine* e) {
     return (uint32_t)b;
 }
 
+template <int GS>
+static void launch_gather(dj_engine* e, const dj_cont* conts, int from_sweep, uint32_t n_fixed, uint32_t cap_conts,
+                          uint64_t cap_pos, int update_ts, uint32_t* lens, uint32_t* mws, uint8_t* payloads,
+                          dj_sweep_result* res) {
+    const uint64_t n = from_sweep ? cap_conts : n_fixed;
+    uint64_t blocks = (n * GS + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    gather_kernel<GS><<<(uint32_t)blocks, 256, 0, e->stream>>>(e->t, e->w, conts, from_sweep, n_fixed, cap_conts, cap_pos,
+                                                                update_ts, lens, mws, payloads, res);
+}
+
+static void dispatch_gather(dj_engine* e, const dj_cont* conts, int from_sweep, uint32_t n_fixed, uint32_t cap_conts,
+                            uint64_t cap_pos, int update_ts, uint32_t* lens, uint32_t* mws, uint8_t* payloads,
+                            dj_sweep_result* res) {
+    // lanes per continuation from the largest continuation the engine can hold (16-byte chunks)
+    const uint64_t items = (uint64_t)e->cfg.max_count * (e->cfg.payload_stride / 16);
+    if (items <= 64) launch_gather<8>(e, conts, from_sweep, n_fixed, cap_conts, cap_pos, update_ts, lens, mws, payloads, res);
+    else if (items <= 512) launch_gather<16>(e, conts, from_sweep, n_fixed, cap_conts, cap_pos, update_ts, lens, mws, payloads, res);
+    else launch_gather<64>(e, conts, from_sweep, n_fixed, cap_conts, cap_pos, update_ts, lens, mws, payloads, res);
+}
+
 static int sweep_impl(dj_engine* e, const char* what, uint64_t now_ms, uint32_t cap_conts, uint64_t cap_positions,
                       int gather, dj_cont* d_conts, uint32_t* d_lens, uint32_t* d_max_waits, uint8_t* d_payloads,
                       dj_sweep_result* d_result, dj_sweep_result* h_result) {
@@ -343,18 +375,20 @@ static int sweep_impl(dj_engine* e, const char* what, uint64_t now_ms, uint32_t 
     if (cap_conts > e->t.mask + 1) cap_conts = (uint32_t)(e->t.mask + 1);
     if (gather) {
         if (cap_positions < e->cfg.max_count) return fail(e, DJ_E_INVALID, "%s: cap_positions must be >= max_count", what);
+        if (cap_positions > (1ull << 32)) cap_positions = 1ull << 32;
         if (d_payloads && !aligned16(d_payloads)) return fail(e, DJ_E_INVALID, "%s: payload buffer must be 16-byte aligned", what);
     }
     dj_sweep_result* res = d_result ? d_result : e->d_result;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
-    HIP_TRY(e, hipMemsetAsync(res, 0, sizeof(dj_sweep_result), e->stream));
-    LAUNCH(e, DJ_PROF_POP, (pop_due_kernel<<<pop_blocks(e), 256, 0, e->stream>>>(e->t, e->w, now_ms, cap_conts, cap_positions, gather, d_conts, res)));
-    finish_result_kernel<<<1, 64, 0, e->stream>>>(res, cap_conts, cap_positions, gather);
-    if (gather) {
-        uint32_t blocks = grid_for((uint64_t)cap_conts * 64, 256);
-        if (blocks > 16384) blocks = 16384;
-        LAUNCH(e, DJ_PROF_GATHER, (gather_kernel<<<blocks, 256, 0, e->stream>>>(e->t, e->w, d_conts, res, 0, 1, d_lens, d_max_waits, d_payloads)));
-    }
+    // double-banked cursors: this sweep counts in one bank, its last kernel zeroes the other
+    e->w.sweep = e->d_sweep + e->sweep_bank * S_COUNT;
+    e->w.sweep_next = e->d_sweep + (e->sweep_bank ^ 1) * S_COUNT;
+    e->sweep_bank ^= 1;
+    LAUNCH(e, DJ_PROF_POP, (pop_due_kernel<<<pop_blocks(e), 256, 0, e->stream>>>(e->t, e->w, now_ms, cap_conts, cap_positions, gather, d_conts)));
+    if (gather)
+        LAUNCH(e, DJ_PROF_GATHER, dispatch_gather(e, d_conts, 1, 0, cap_conts, cap_positions, 1, d_lens, d_max_waits, d_payloads, res));
+    else
+        finish_result_kernel<<<1, 64, 0, e->stream>>>(e->w, res, cap_conts, 0);
     HIP_TRY(e, hipGetLastError());
     if (h_result) {
         HIP_TRY(e, hipMemcpyAsync(h_result, res, sizeof(dj_sweep_result), hipMemcpyDeviceToHost, e->stream));
@@ -382,7 +416,6 @@ extern "C" int dj_ack_batch(dj_engine* e, uint32_t n, const uint32_t* d_n, const
     if (n == 0) return DJ_OK;
     if (!d_conts || !d_status) return fail(e, DJ_E_INVALID, "ack: null pointer");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
-    snapshot_tails_kernel<<<1, 64, 0, e->stream>>>(e->t);
     LAUNCH(e, DJ_PROF_ACK, (ack_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, n, d_n, d_conts, d_ok, now_ms, d_status)));
     HIP_TRY(e, hipGetLastError());
     return DJ_OK;
@@ -396,9 +429,8 @@ extern "C" int dj_recover(dj_engine* e, uint64_t now_ms, uint32_t cap, dj_cont* 
     dj_sweep_result* res = d_result ? d_result : e->d_result;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     HIP_TRY(e, hipMemsetAsync(res, 0, sizeof(dj_sweep_result), e->stream));
-    snapshot_tails_kernel<<<1, 64, 0, e->stream>>>(e->t);
     LAUNCH(e, DJ_PROF_RECOVER, (recover_kernel<<<scan_blocks(e), 256, 0, e->stream>>>(e->t, now_ms, cap, d_conts, d_status, res)));
-    finish_result_kernel<<<1, 64, 0, e->stream>>>(res, cap, 0, 0);
+    clamp_count_kernel<<<1, 64, 0, e->stream>>>(res, cap);
     HIP_TRY(e, hipGetLastError());
     if (h_result) {
         HIP_TRY(e, hipMemcpyAsync(h_result, res, sizeof(dj_sweep_result), hipMemcpyDeviceToHost, e->stream));
@@ -413,8 +445,8 @@ extern "C" int dj_snapshot_one(dj_engine* e, uint64_t fp_lo, uint64_t fp_hi, int
     if (!e || !h_meta) return DJ_E_INVALID;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     lookup_one_kernel<<<1, 64, 0, e->stream>>>(e->t, e->w, fp_lo, fp_hi, e->d_one_cont, e->d_one_scores);
-    gather_kernel<<<1, 64, 0, e->stream>>>(e->t, e->w, e->d_one_cont, nullptr, 1, update_ts ? 1 : 0, e->d_one_lens,
-                                           e->d_one_mws, h_payloads ? e->d_one_payload : nullptr);
+    gather_kernel<64><<<1, 64, 0, e->stream>>>(e->t, e->w, e->d_one_cont, 0, 1, 1, e->cfg.max_count, update_ts ? 1 : 0,
+                                               e->d_one_lens, e->d_one_mws, h_payloads ? e->d_one_payload : nullptr, nullptr);
     HIP_TRY(e, hipGetLastError());
     HIP_TRY(e, hipMemcpyAsync(h_meta, e->d_one_cont, sizeof(dj_cont), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));

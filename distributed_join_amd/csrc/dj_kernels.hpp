@@ -16,6 +16,9 @@ namespace dj {
 __global__ void __launch_bounds__(256) fork_claim_kernel(Table t, Work w, const dj_fork_rec* recs, uint32_t n,
                                                          int32_t* status) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // ring pops of the apply pass stop at the tails as they are now (nothing is pushed or popped
+    // during this pass), see wave_slab_alloc
+    if (blockIdx.x == 0 && threadIdx.x < NUM_CLASSES) t.ring_tail_snap[threadIdx.x] = t.ring_tail[threadIdx.x];
     if (i >= n) return;
     const ulonglong2 a = reinterpret_cast<const ulonglong2*>(recs)[2 * (size_t)i];
     const uint32_t count = recs[i].count;
@@ -37,8 +40,11 @@ __global__ void __launch_bounds__(256) fork_claim_kernel(Table t, Work w, const 
 }
 
 // pass 2: the winning record of each slot resets the barrier.
-__global__ void __launch_bounds__(256) fork_apply_kernel(Table t, Work w, const dj_fork_rec* recs, uint32_t n,
-                                                         int32_t* status) {
+constexpr int FORK_APPLY_BLOCK = 1024;
+
+__global__ void __launch_bounds__(FORK_APPLY_BLOCK) fork_apply_kernel(Table t, Work w, const dj_fork_rec* recs, uint32_t n,
+                                                                      int32_t* status) {
+    __shared__ uint32_t lds[24];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     // phase A (per lane): is this record the winner of its slot, and does the slot need a new slab
     bool active = false, need = false;
@@ -57,8 +63,8 @@ __global__ void __launch_bounds__(256) fork_apply_kernel(Table t, Work w, const 
         k_old = class_of(sl->count);
         need = old_slab == 0 || k_old != k_new;
     }
-    // phase B (wave-cooperative): one atomic per size class / per wave
-    const uint32_t fresh = wave_slab_alloc(t, need, k_new);
+    // phase B (block-cooperative): one ring pop + one bump add per block
+    const uint32_t fresh = block_slab_alloc(t, need, k_new, lds);
     wave_slab_free(t, need && fresh != 0, k_old, old_slab);
     if (!active) return;
     // phase C (per lane)
@@ -68,7 +74,7 @@ __global__ void __launch_bounds__(256) fork_apply_kernel(Table t, Work w, const 
             // engine limit, no counterpart in the reference: report it and leave the table as it was
             status[i] = DJ_FORK_NO_SPACE;
             sl->chain = 0;
-            if (!(sl->meta & META_HAS) && t.q_primary[s] == NQ && t.q_backup[s] == NQ) clear_slot(t, s);
+            if (!(sl->meta & META_HAS) && t.q[s] == Q_NONE) clear_slot(t, s);
             return;
         }
         slab = fresh;
@@ -85,8 +91,7 @@ __global__ void __launch_bounds__(256) fork_apply_kernel(Table t, Work w, const 
     sl->join_ts = 0;                                      // DEL <id>:join-ts
     sl->join_ts_read = 0;                                 // DEL <id>:join-ts-read
     sl->bits = 0;                                         // DEL <id>
-    t.q_backup[s] = r.deadline_ms;                        // ZREM both, then ZADD both (redis.clj:257-258)
-    t.q_primary[s] = r.deadline_ms;
+    t.q[s] = r.deadline_ms;                               // ZREM both, then ZADD both (redis.clj:257-258)
 }
 
 // =====================================================================================
@@ -140,8 +145,12 @@ __global__ void __launch_bounds__(LINK_BLOCK) join_link_kernel(Table t, Work w, 
         }
         if (st != 0) {
             status[i] = st;
-            w.dst[i] = NODST;      // accepted events get their dst from the resolve pass
+            w.dst[i] = NODST;
         } else {
+            // the common answers are written here, coalesced; the resolve pass only overwrites the
+            // exceptions (COMPLETE / NEAREST_NOT_QUEUED statuses, superseded messages)
+            status[i] = DJ_JOIN_WAITING;
+            w.dst[i] = dst_pack(t.slots[s].slab, t.slots[s].count);
             uint32_t prev = a_xchg(&t.slots[s].chain, i + 1);
             w.node[i] = node_pack(prev, b.x, b.z);
             first = prev == 0;
@@ -177,7 +186,7 @@ __device__ inline int32_t replay_one(const Table& t, uint64_t s, uint32_t slab, 
         return DJ_JOIN_COMPLETE;
     }
     if (mw) {                                // join-with-max-wait, core.clj:40-42
-        if (!r.pa_loaded) { r.pa = t.q_primary[s]; r.pa_loaded = true; }
+        if (!r.pa_loaded) { r.pa = q_primary_at(t.q[s]); r.pa_loaded = true; }
         if (r.pa == NQ) return DJ_JOIN_NEAREST_NOT_QUEUED;   // ZSCORE nil: the Lua compare raises (redis.clj:268-269)
         uint64_t at = now + 1000ull * mw;
         if (r.pa > at) { r.pa = at; r.pa_dirty = true; }     // redis.clj:269-271
@@ -228,24 +237,24 @@ __global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint
             r.bits = count > 64 ? 0 : sl->bits;
             r.arrived = count > 64 ? (uint32_t)sl->bits : (uint32_t)__popcll(sl->bits);
             r.pa = NQ; r.pa_loaded = false; r.pa_dirty = false; r.enq = false;
-            const uint64_t d = dst_pack(slab, count);
 #pragma unroll
             for (int k = 0; k < CHAIN_REG; ++k) {
                 if (k < m) {
                     const uint32_t pos = node_pos(nd[k]);
-                    status[idx[k]] = replay_one(t, s, slab, r, pos, node_mw(nd[k]), now);
+                    const int32_t st = replay_one(t, s, slab, r, pos, node_mw(nd[k]), now);
+                    if (st != DJ_JOIN_WAITING) status[idx[k]] = st;
                     bool last = true;   // last writer of its position inside the batch
 #pragma unroll
                     for (int j = k + 1; j < CHAIN_REG; ++j)
                         if (j < m && node_pos(nd[j]) == pos) last = false;
-                    w.dst[idx[k]] = last ? d : NODST;
+                    if (!last) w.dst[idx[k]] = NODST;
                 }
             }
             sl->bits = count > 64 ? (uint64_t)r.arrived : r.bits;
             sl->join_ts = now;                              // SET <id>:join-ts, redis.clj:136
             sl->chain = 0;
-            if (r.enq) { t.q_backup[s] = now; t.q_primary[s] = now; }          // redis.clj:257-258
-            else if (r.pa_dirty) { t.q_backup[s] = r.pa; t.q_primary[s] = r.pa; }  // redis.clj:270-271
+            if (r.enq) t.q[s] = now;                    // ZADD both at now, redis.clj:257-258
+            else if (r.pa_dirty) t.q[s] = r.pa;         // ZADD both at the nearer date, redis.clj:270-271
         }
     }
     uint32_t at = wave_append(&w.counters[C_COMPLEX], is_complex);
@@ -315,8 +324,7 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
             uint32_t T = IDX_NONE;
             if (arrived_pre == count) T = 0;
             else if (arrived == count) T = t_complete;
-            const uint64_t pa_pre = t.q_primary[s];
-            const uint64_t d = dst_pack(slab, count);
+            const uint64_t pa_pre = q_primary_at(t.q[s]);
             for (uint32_t cur = head; cur != 0;) {
                 const uint64_t x = w.node[cur - 1];
                 const uint32_t i = cur - 1, pos = node_pos(x), mw = node_mw(x);
@@ -327,15 +335,15 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
                     st = DJ_JOIN_WAITING;
                     if (mw) { uint64_t at = now + 1000ull * mw; if (at < at_min) at_min = at; }
                 }
-                status[i] = st;
-                w.dst[i] = fmax[pos] == i + 1 ? d : NODST;
+                if (st != DJ_JOIN_WAITING) status[i] = st;
+                if (fmax[pos] != i + 1) w.dst[i] = NODST;
                 cur = node_next(x);
             }
             sl->bits = count > 64 ? (uint64_t)arrived : bits0;
             sl->join_ts = now;
             sl->chain = 0;
-            if (T != IDX_NONE) { t.q_backup[s] = now; t.q_primary[s] = now; }
-            else if (pa_pre != NQ && at_min < pa_pre) { t.q_backup[s] = at_min; t.q_primary[s] = at_min; }
+            if (T != IDX_NONE) t.q[s] = now;
+            else if (pa_pre != NQ && at_min < pa_pre) t.q[s] = at_min;
         }
         __syncthreads();
     }
@@ -351,6 +359,8 @@ __global__ void __launch_bounds__(256) join_copy_kernel(Table t, Work w, const d
     const uint32_t sub = lane / G, j0 = lane % G;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    // the next batch's counters (the bank this batch does not use) start at zero
+    if (blockIdx.x == 0 && threadIdx.x < C_COUNT) w.counters_next[threadIdx.x] = 0;
     for (uint64_t base = wave * EPW; base < n; base += waves * EPW) {
         const uint64_t i = base + sub;
         if (i >= n) continue;
@@ -371,12 +381,13 @@ __global__ void __launch_bounds__(256) join_copy_kernel(Table t, Work w, const d
 // join-metadata, timeout classification (core.clj:86-95) and redis/all-joins (redis.clj:210-243)
 // =====================================================================================
 
-__device__ inline void fill_cont(dj_cont* c, const Slot& sl, uint64_t now, uint64_t publish_at, uint64_t pos_base) {
+__device__ inline void fill_cont(dj_cont* c, const Slot& sl, uint64_t now, uint64_t publish_at, uint64_t pos_base,
+                                 uint64_t slot_hint = 0) {
     c->fp_lo = sl.fp_lo;
     c->fp_hi = sl.fp_hi;
     c->publish_at = publish_at;
     c->pos_base = pos_base;
-    c->reserved = 0;
+    c->reserved = slot_hint;     // slot index + 1: lets the ack find the barrier without probing
     if (sl.meta & META_HAS) {
         c->deadline_ms = sl.deadline;
         c->count = sl.count;
@@ -392,18 +403,17 @@ __device__ inline void fill_cont(dj_cont* c, const Slot& sl, uint64_t now, uint6
     }
 }
 
-// One pass over q_primary: every slot with score <= now is popped (ZRANGEBYSCORE +
-// ZREMRANGEBYSCORE 0 now).  A block scans chunks of 256 * POP_ITEMS slots; output indices for a
-// chunk come from a block-wide prefix sum and ONE atomic pair per chunk.  res->n_conts /
-// n_positions are the raw cursors until finish_result_kernel clamps them.
-constexpr int POP_ITEMS = 8;
+// One pass over q[]: every slot with q <= now (in the primary queue, score <= now) is popped
+// (ZRANGEBYSCORE + ZREMRANGEBYSCORE 0 now).  A block scans chunks of 256 * POP_ITEMS slots;
+// output indices for a chunk come from a block-wide prefix sum and ONE atomic on the packed
+// cursor word.  The cursors are raw (they may run past the caps); the gather pass (or
+// finish_result_kernel) publishes the clamped dj_sweep_result.
+constexpr int POP_ITEMS = 4;
 
 __global__ void __launch_bounds__(256) pop_due_kernel(Table t, Work w, uint64_t now, uint32_t cap_conts,
-                                                      uint64_t cap_pos, int alloc_pos, dj_cont* conts,
-                                                      dj_sweep_result* res) {
+                                                      uint64_t cap_pos, int alloc_pos, dj_cont* conts) {
     __shared__ uint32_t wave_c[4], wave_p[4];
-    __shared__ uint32_t base_c_s;
-    __shared__ unsigned long long base_p_s;
+    __shared__ unsigned long long base_s;
     const uint64_t nslots = t.mask + 1;
     const uint64_t chunk = 256ull * POP_ITEMS;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -414,9 +424,9 @@ __global__ void __launch_bounds__(256) pop_due_kernel(Table t, Work w, uint64_t 
         for (int j = 0; j < POP_ITEMS; ++j) {
             const uint64_t s = cb + (uint64_t)j * 256 + tid;
             cnts[j] = 0;
-            if (s < nslots && t.q_primary[s] <= now) {
+            if (s < nslots && t.q[s] <= now) {
                 const uint2 cm = *reinterpret_cast<const uint2*>(&t.slots[s].count);   // count, meta
-                cnts[j] = (cm.y & META_HAS) ? cm.x : 0;
+                cnts[j] = (alloc_pos && (cm.y & META_HAS)) ? cm.x : 0;
                 due_mask |= 1u << j;
                 ++nd;
                 ps += cnts[j];
@@ -426,14 +436,13 @@ __global__ void __launch_bounds__(256) pop_due_kernel(Table t, Work w, uint64_t 
         if (lane == 63) { wave_c[wv] = incl_c; wave_p[wv] = incl_p; }
         __syncthreads();
         if (tid == 0) {
-            const uint32_t tc = wave_c[0] + wave_c[1] + wave_c[2] + wave_c[3];
-            const uint32_t tp = wave_p[0] + wave_p[1] + wave_p[2] + wave_p[3];
-            base_c_s = tc ? a_add(&res->n_conts, tc) : 0u;
-            base_p_s = (alloc_pos && tp) ? a_add((unsigned long long*)&res->n_positions, (unsigned long long)tp) : 0ull;
+            const unsigned long long tc = wave_c[0] + wave_c[1] + wave_c[2] + wave_c[3];
+            const unsigned long long tp = wave_p[0] + wave_p[1] + wave_p[2] + wave_p[3];
+            base_s = tc ? a_add(&w.sweep[S_CURSOR], tc | (tp << CURSOR_SHIFT)) : 0ull;
         }
         __syncthreads();
-        uint32_t my_c = base_c_s + incl_c - nd;
-        uint64_t my_p = base_p_s + incl_p - ps;
+        uint32_t my_c = (uint32_t)(base_s & CURSOR_CONT_MASK) + incl_c - nd;
+        uint64_t my_p = (base_s >> CURSOR_SHIFT) + incl_p - ps;
         for (uint32_t v = 0; v < wv; ++v) { my_c += wave_c[v]; my_p += wave_p[v]; }
 #pragma unroll
         for (int j = 0; j < POP_ITEMS; ++j) {
@@ -442,72 +451,88 @@ __global__ void __launch_bounds__(256) pop_due_kernel(Table t, Work w, uint64_t 
             const uint32_t c_idx = my_c++;
             const uint64_t p_idx = my_p;
             my_p += cnts[j];
-            if (c_idx >= cap_conts) { res->more = 1; continue; }
+            if (c_idx >= cap_conts) { w.sweep[S_MORE] = 1; continue; }
             if (alloc_pos && p_idx + cnts[j] > cap_pos) {
-                res->more = 1;
+                w.sweep[S_MORE] = 1;
                 conts[c_idx].flags = CONT_VOID;      // index taken, barrier stays queued
                 conts[c_idx].count = 0;
                 w.cont_slot[c_idx] = 0xFFFFFFFFu;
                 continue;
             }
-            const uint64_t pa = t.q_primary[s];
-            t.q_primary[s] = NQ;                    // popped; the backup entry stays (redis.clj:288)
-            fill_cont(&conts[c_idx], t.slots[s], now, pa, p_idx);
+            const uint64_t pa = t.q[s];
+            t.q[s] = pa | Q_POPPED;                 // popped; the backup entry stays (redis.clj:288)
+            fill_cont(&conts[c_idx], t.slots[s], now, pa, p_idx, s + 1);
             w.cont_slot[c_idx] = (uint32_t)s;
         }
         __syncthreads();
     }
 }
 
-__global__ void finish_result_kernel(dj_sweep_result* res, uint32_t cap_conts, uint64_t cap_pos, int alloc_pos) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        if (res->n_conts > cap_conts) res->n_conts = cap_conts;
-        if (alloc_pos && res->n_positions > cap_pos) res->n_positions = cap_pos;
-    }
+// clamp the raw cursors into the caller-visible result; resets the other sweep bank
+__device__ inline void publish_result(const Work& w, dj_sweep_result* res, uint32_t cap_conts, uint64_t cap_pos) {
+    const unsigned long long cur = w.sweep[S_CURSOR];
+    const unsigned long long nc = cur & CURSOR_CONT_MASK, np = cur >> CURSOR_SHIFT;
+    res->n_conts = nc > cap_conts ? cap_conts : (uint32_t)nc;
+    res->n_positions = np > cap_pos ? cap_pos : np;
+    res->more = w.sweep[S_MORE] ? 1u : 0u;
+    w.sweep_next[S_CURSOR] = 0;
+    w.sweep_next[S_MORE] = 0;
 }
 
-// redis/all-joins for the popped barriers: one wave per continuation.
+__global__ void finish_result_kernel(Work w, dj_sweep_result* res, uint32_t cap_conts, uint64_t cap_pos) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) publish_result(w, res, cap_conts, cap_pos);
+}
+
+// redis/all-joins for popped barriers (from_sweep: the raw cursor says how many; it also
+// publishes the sweep's result block) or for n_fixed listed continuations.  GS lanes work on
+// one continuation, 64 / GS continuations per wave are in flight together: the pass is bound
+// by chains of dependent loads (continuation -> slot -> slab), not by bytes.
 // update_ts: join-ts-read := join-ts (redis.clj:222-229).
-__global__ void __launch_bounds__(256) gather_kernel(Table t, Work w, const dj_cont* conts,
-                                                     const dj_sweep_result* res, uint32_t n_fixed, int update_ts,
-                                                     uint32_t* lens, uint32_t* max_waits, uint8_t* payloads) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
-    const uint64_t waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    const uint32_t n = res ? res->n_conts : n_fixed;
-    const uint32_t G = t.stride / 16 < 64 ? t.stride / 16 : 64;   // lanes per message (stride is a multiple of 64)
-    const uint32_t rows_per_step = 64 / G;
-    for (uint64_t kc = wave; kc < n; kc += waves) {
+template <int GS>
+__global__ void __launch_bounds__(256) gather_kernel(Table t, Work w, const dj_cont* conts, int from_sweep,
+                                                     uint32_t n_fixed, uint32_t cap_conts, uint64_t cap_pos,
+                                                     int update_ts, uint32_t* lens, uint32_t* max_waits,
+                                                     uint8_t* payloads, dj_sweep_result* res) {
+    uint32_t n = n_fixed;
+    if (from_sweep) {
+        const unsigned long long nc = w.sweep[S_CURSOR] & CURSOR_CONT_MASK;
+        n = nc > cap_conts ? cap_conts : (uint32_t)nc;
+    }
+    const uint64_t gtid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    const uint64_t group = gtid / GS, groups = ((uint64_t)gridDim.x * blockDim.x) / GS;
+    const uint32_t j = (uint32_t)(gtid % GS);
+    const uint32_t CH = t.stride >> 4;                      // 16-byte chunks per position row
+    for (uint64_t kc = group; kc < n; kc += groups) {
         const uint32_t s = w.cont_slot[kc];
         if (s == 0xFFFFFFFFu) continue;
-        const dj_cont c = conts[kc];
-        if (c.flags & (DJ_CONT_NO_METADATA | CONT_VOID)) continue;
+        const uint4 head = reinterpret_cast<const uint4*>(&conts[kc])[2];      // count, flags, retry counters
+        if (head.y & (DJ_CONT_NO_METADATA | CONT_VOID)) continue;
+        const uint64_t pos_base = conts[kc].pos_base;
         Slot* sl = &t.slots[s];
-        if (update_ts && lane == 0) sl->join_ts_read = sl->join_ts;
-        const uint32_t count = c.count, slab = sl->slab, k = class_of(count);
+        const uint32_t count = head.x, slab = sl->slab, k = class_of(count);
         const uint64_t bits0 = sl->bits;
+        if (update_ts && j == 0) sl->join_ts_read = sl->join_ts;
         const uint64_t* bm = slab_bitmap(t, slab);
         const uint2* pm = slab_posmeta(t, slab, k);
         const uint8_t* pay = slab_payload(t, slab, k);
-        for (uint32_t p = lane; p < count; p += 64) {
+        for (uint32_t p = j; p < count; p += GS) {
             const bool present = count > 64 ? ((bm[p >> 6] >> (p & 63)) & 1) : ((bits0 >> p) & 1);
             const uint2 meta = present ? pm[p] : make_uint2(DJ_NIL, 0);
-            if (lens) lens[c.pos_base + p] = meta.x;
-            if (max_waits) max_waits[c.pos_base + p] = meta.y;
+            if (lens) lens[pos_base + p] = meta.x;
+            if (max_waits) max_waits[pos_base + p] = meta.y;
         }
         if (!payloads) continue;
-        const uint32_t sub = lane / G, j0 = lane % G;
-        for (uint32_t p0 = 0; p0 < count; p0 += rows_per_step) {
-            const uint32_t p = p0 + sub;
-            if (p >= count) continue;
+        // (position, chunk) pairs flattened over the group's lanes
+        const uint32_t items = count * CH;
+        for (uint32_t it = j; it < items; it += GS) {
+            const uint32_t p = it / CH, ch = it - p * CH;
             const bool present = count > 64 ? ((bm[p >> 6] >> (p & 63)) & 1) : ((bits0 >> p) & 1);
-            if (!present) continue;
-            const uint32_t chunks = (pm[p].x + 15) >> 4;
-            const uint4* src = reinterpret_cast<const uint4*>(pay + (uint64_t)p * t.stride);
-            uint4* dstp = reinterpret_cast<uint4*>(payloads + (c.pos_base + p) * (uint64_t)t.stride);
-            for (uint32_t ch = j0; ch < chunks; ch += G) dstp[ch] = src[ch];
+            if (!present || ch >= ((pm[p].x + 15) >> 4)) continue;
+            reinterpret_cast<uint4*>(payloads + (pos_base + p) * (uint64_t)t.stride)[ch] =
+                reinterpret_cast<const uint4*>(pay + (uint64_t)p * t.stride)[ch];
         }
     }
+    if (from_sweep && res && gtid == 0) publish_result(w, res, cap_conts, cap_pos);
 }
 
 // =====================================================================================
@@ -523,8 +548,7 @@ __device__ inline bool complete_decide(const Table& t, uint64_t s, uint64_t now)
     if (sl->join_ts == sl->join_ts_read) return true;          // two nils compare equal
     // reset-publish: both retry counters dropped, :publish-retry-cnt 0, re-queued at now
     sl->meta = meta_pack(sl->meta & META_HAS, 0, RETRY_NIL);
-    t.q_backup[s] = now;
-    t.q_primary[s] = now;
+    t.q[s] = now;
     return false;
 }
 
@@ -542,8 +566,7 @@ __device__ inline void retry_requeue(const Table& t, uint64_t s, bool timeout, u
                                      uint64_t now) {
     if (timeout) rt = cnt + 1; else rp = cnt + 1;
     t.slots[s].meta = meta_pack(true, rp, rt);
-    t.q_backup[s] = now;
-    t.q_primary[s] = now;
+    t.q[s] = now;
 }
 
 __global__ void __launch_bounds__(256) ack_kernel(Table t, uint32_t n_max, const uint32_t* d_n, const dj_cont* conts,
@@ -570,7 +593,12 @@ __global__ void __launch_bounds__(256) ack_kernel(Table t, uint32_t n_max, const
             deleted_code = DJ_ACK_DROPPED_EXHAUSTED;
         }
         if (complete_path) {
-            const int64_t s = find_slot(t, c.fp_lo, c.fp_hi);
+            int64_t s = -1;
+            if (c.reserved && c.reserved - 1 <= t.mask) {      // slot hint written by the sweep
+                const Slot* hs = &t.slots[c.reserved - 1];
+                if (hs->fp_lo == c.fp_lo && hs->fp_hi == c.fp_hi) s = (int64_t)(c.reserved - 1);
+            }
+            if (s < 0) s = find_slot(t, c.fp_lo, c.fp_hi);
             if (s < 0) {
                 st = deleted_code;                     // nothing left to delete
             } else if (complete_decide(t, (uint64_t)s, now)) {
@@ -594,7 +622,7 @@ __global__ void __launch_bounds__(256) ack_kernel(Table t, uint32_t n_max, const
                 if (created) {
                     sl->count = 0; sl->meta = 0; sl->slab = 0; sl->chain = 0;
                     sl->deadline = 0; sl->join_ts = 0; sl->join_ts_read = 0; sl->bits = 0;
-                    t.q_primary[s] = NQ; t.q_backup[s] = NQ;
+                    t.q[s] = Q_NONE;
                 }
                 write_back = true;
                 k_new = class_of(c.count);
@@ -645,8 +673,9 @@ __global__ void __launch_bounds__(256) recover_kernel(Table t, uint64_t now, uin
     const uint64_t max_score = now - t.check_publish_delay_ms;
     // all lanes of a wave iterate together (nslots is a multiple of the grid's wave size)
     for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < nslots; s += stride) {
-        const uint64_t ba = t.q_backup[s];
-        const bool due = ba <= max_score;
+        const uint64_t qv = t.q[s];
+        const uint64_t ba = q_backup_at(qv);
+        const bool due = qv != Q_NONE && ba <= max_score;
         if (__ballot(due) == 0) continue;
         const uint32_t at = wave_append(&res->n_conts, due);
         int32_t st = 0;
@@ -681,7 +710,7 @@ __global__ void __launch_bounds__(256) recover_kernel(Table t, uint64_t now, uin
         if (clear) clear_slot(t, s);
         if (due) {
             if (at < cap) {
-                fill_cont(&conts[at], sl, now, ba, 0);
+                fill_cont(&conts[at], sl, now, ba, 0, s + 1);
                 status[at] = st;
             } else {
                 res->more = 1;
@@ -727,11 +756,11 @@ __global__ void lookup_one_kernel(Table t, Work w, uint64_t lo, uint64_t hi, dj_
         w.cont_slot[0] = 0xFFFFFFFFu;
         return;
     }
-    fill_cont(cont, t.slots[s], 0, t.q_primary[s], 0);
+    fill_cont(cont, t.slots[s], 0, q_primary_at(t.q[s]), 0, (uint64_t)s + 1);
     cont->flags &= ~DJ_CONT_TIMEOUT;
     w.cont_slot[0] = (uint32_t)s;
-    scores[0] = t.q_primary[s];
-    scores[1] = t.q_backup[s];
+    scores[0] = q_primary_at(t.q[s]);
+    scores[1] = q_backup_at(t.q[s]);
 }
 
 // redis/store-in-publish-queue for one id (redis.clj:255-259); creates a metadata-less slot
@@ -746,13 +775,12 @@ __global__ void store_in_queue_one_kernel(Table t, uint64_t lo, uint64_t hi, uin
         sl->count = 0; sl->meta = 0; sl->slab = 0; sl->chain = 0;
         sl->deadline = 0; sl->join_ts = 0; sl->join_ts_read = 0; sl->bits = 0;
     }
-    t.q_backup[s] = at;
-    t.q_primary[s] = at;
+    t.q[s] = at;
     *err = 0;
 }
 
-__global__ void snapshot_tails_kernel(Table t) {
-    if (threadIdx.x < NUM_CLASSES && blockIdx.x == 0) t.ring_tail_snap[threadIdx.x] = t.ring_tail[threadIdx.x];
+__global__ void clamp_count_kernel(dj_sweep_result* res, uint32_t cap) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && res->n_conts > cap) res->n_conts = cap;
 }
 
 // =====================================================================================
