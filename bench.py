@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--payload", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--route", action="store_true",
+                    help="run the multi-GPU routing path (partition + all-to-all) even with one rank")
     return ap.parse_args()
 
 
@@ -84,8 +86,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    routed = world > 1 or a.route
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    elif a.route:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29400 + os.getpid() % 500}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -119,7 +125,7 @@ def main():
 
     # ---- engine ------------------------------------------------------------------------------
     slab_bytes = 64 * (1 + (8 * (1 << (c - 1).bit_length()) + 63) // 64) + (1 << (c - 1).bit_length()) * stride
-    recv_cap = batch if world == 1 else int(batch * 1.25) + 4096
+    recv_cap = batch if world == 1 else int(batch * 1.25) + 4096       # hash imbalance headroom
     eng = Engine(capacity_barriers=int(nb * (1.0 if world == 1 else 1.25)) + 1024,
                  arena_bytes=int(nb * (1.0 if world == 1 else 1.3) * (slab_bytes + 64)) + (64 << 20), max_count=c,
                  payload_stride=stride, max_batch=max(recv_cap, nb * 2 if world > 1 else nb), device=local)
@@ -135,7 +141,7 @@ def main():
     es = eng.torch_stream()
 
     router = None
-    if world > 1:
+    if routed:
         from distributed_join_amd.router import Router
         router = Router(eng, dist.group.WORLD, max_send=batch, max_recv=max(recv_cap, nb * 2), pitch=pitch)
 
@@ -255,14 +261,15 @@ def main():
             "config": {"workload": f"configs[1]: {nb} barriers x count {c} per GPU, {P} B messages, uniform arrival, "
                                    f"no timeouts; step = {batch} joins + sweep/gather + ack, fork of {nb} barriers every "
                                    f"{steps_per_job} steps", "barriers_per_gpu": nb, "count": c, "payload_bytes": P,
-                       "batch": batch, "sharding": "none" if world == 1 else f"fingerprint hash over {world} GPUs, all-to-all"},
+                       "batch": batch,
+                       "sharding": "none" if not routed else f"fingerprint hash over {world} GPU(s), partition + all-to-all"},
             "continuations_per_s": float(fired.item()) / elapsed_s,
             "continuations_fired": int(fired.item()),
             "gpu_stream_ms": gpu_ms,
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
+    if routed:
         dist.destroy_process_group()
     eng.close()
 

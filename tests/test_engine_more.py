@@ -204,3 +204,86 @@ def test_config2_full_size_properties():
         assert s["live"] == 0 and s["tombstones"] == nb
     finally:
         e.close()
+
+
+def test_router_single_rank_roundtrip():
+    """The multi-GPU routing path with one RCCL rank: partition kernels + all_to_all_single must hand
+    every record (and its message) to the only owner, in array order."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from distributed_join_amd.router import Router
+    n, pitch = 50_000, 64
+    rng = np.random.default_rng(9)
+    e = _engine(capacity_barriers=64, arena_bytes=1 << 20, max_count=8, payload_stride=64, max_batch=1 << 16)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29600 + os.getpid() % 300}", rank=0, world_size=1,
+                            device_id=e.device)
+    try:
+        recs = torch.from_numpy(rng.integers(2, 1 << 62, (n, 4), dtype=np.int64)).to(e.device)
+        pay = torch.from_numpy(rng.integers(0, 256, (n, pitch), dtype=np.uint8)).to(e.device)
+        r = Router(e, dist.group.WORLD, max_send=n, max_recv=n, pitch=pitch)
+        rr, rp, n_in = r.route(recs, pay, n)
+        assert n_in == n
+        assert torch.equal(rr[:n], recs) and torch.equal(rp[:n], pay)
+        rr, rp, n_in = r.route(recs[:1000], None, 1000)
+        assert n_in == 1000 and rp is None and torch.equal(rr[:1000], recs[:1000])
+    finally:
+        dist.destroy_process_group()
+        e.close()
+
+
+def test_config5_shape_scaled(oracle_lib):
+    """BASELINE config #5 scaled: join-ids drawn Zipf(1.2) over 1 K ids, 1 % of the events on one
+    hot barrier, 10 % of the joins replayed byte-identically, 1 % re-sent with different bytes (last
+    writer wins), some replays landing between a sweep and its ack (at-least-once: the barrier fires
+    again), 1 KB messages."""
+    rng = np.random.default_rng(5)
+    n_join_ids, n_tx, c, P = 1000, 4, 16, 1024
+    nb = n_join_ids * n_tx
+    ids = [f"j{b // n_tx:x}~t{b % n_tx:x}" for b in range(nb)]
+    e = _engine(capacity_barriers=nb, arena_bytes=256 << 20, max_count=c, payload_stride=P, max_batch=1 << 16,
+                host_cap_conts=1 << 13, host_cap_positions=1 << 17)
+    o = oracle_lib.Oracle(ids, max_count=c, payload_stride=P)
+    d = ParityDriver(e, o, ids)
+    try:
+        now = T0
+        d.fork(np.arange(nb), np.full(nb, c), np.full(nb, T0 + 3_600_000))
+        w = 1.0 / np.arange(1, n_join_ids + 1) ** 1.2
+        w /= w.sum()
+        hot = 7
+        history_b, history_p, history_v = [], [], []
+        fired_twice = 0
+        pending = None
+        version = 0
+        seen_statuses = set()
+        for rnd in range(30):
+            now += 3
+            n = 4000
+            jb = rng.choice(n_join_ids, size=n, p=w) * n_tx + rng.integers(0, n_tx, n)
+            jb[rng.random(n) < 0.01] = hot
+            jp = rng.integers(0, c, n)
+            ver = np.full(n, version)
+            version += 1
+            if history_b:
+                hb, hp, hv = np.concatenate(history_b), np.concatenate(history_p), np.concatenate(history_v)
+                rep = rng.random(n) < 0.10                 # byte-identical replay of an earlier join
+                pick = rng.integers(0, len(hb), n)
+                jb[rep], jp[rep], ver[rep] = hb[pick[rep]], hp[pick[rep]], hv[pick[rep]]
+                chg = rng.random(n) < 0.01                 # same (barrier, position), different bytes
+                jb[chg], jp[chg] = hb[pick[chg]], hp[pick[chg]]
+                ver[chg] = version + 1000
+            history_b.append(jb.copy()); history_p.append(jp.copy()); history_v.append(ver.copy())
+            st = d.join(jb, jp, np.full(n, P), np.zeros(n, np.int64), payload_bytes(jb, jp, ver, P), now)
+            seen_statuses |= set(st.tolist())
+            if pending is not None:
+                # these joins landed between the previous sweep and its ack
+                ec, oc = pending
+                out = d.ack(ec, oc, lambda k: True, now + 1)
+                fired_twice += sum(1 for v in out.values() if v == capi.DJ_ACK_REQUEUED_DIRTY)
+            pending = d.sweep(now + 2)
+        d.ack(pending[0], pending[1], lambda k: True, now + 3)
+        assert fired_twice > 0, "no replay landed between a sweep and its ack"
+        assert {capi.DJ_JOIN_WAITING, capi.DJ_JOIN_COMPLETE, capi.DJ_JOIN_NOT_FOUND} <= seen_statuses
+        d.check_all_snapshots(range(0, nb, 7))
+    finally:
+        e.close()
