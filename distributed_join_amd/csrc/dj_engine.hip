@@ -33,6 +33,9 @@ struct dj_engine {
     int n_allocs;
     std::string err;
     // optional per-kernel timing (dj_profile_enable): one event pair per kernel id
+    Slot* slots_alt;             // second table for dj_compact (always all-empty between calls)
+    uint64_t* q_alt;
+    uint64_t used_upper;         // upper bound of non-empty slots (live + tombstones) since the last compaction
     int ctr_bank, sweep_bank;    // which half of the double-banked scratch the next call uses
     unsigned int* d_counters;    // 2 x C_COUNT
     unsigned long long* d_sweep; // 2 x S_COUNT
@@ -166,6 +169,11 @@ static int create_impl(dj_engine* e) {
     if (t.arena_units >= (1ull << 32)) return fail(e, DJ_E_INVALID, "arena_bytes too large (max 256 GiB)");
     ALLOC(e, t.slots, slots * sizeof(Slot));
     ALLOC(e, t.q, slots * 8);
+    ALLOC(e, e->slots_alt, slots * sizeof(Slot));
+    ALLOC(e, e->q_alt, slots * 8);
+    HIP_TRY(e, hipMemsetAsync(e->slots_alt, 0, slots * sizeof(Slot), e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->q_alt, 0xFF, slots * 8, e->stream));
+    e->used_upper = 0;
     ALLOC(e, t.arena, t.arena_units * 64);
     ALLOC(e, t.bump, 8);
     ALLOC(e, t.ring_head, NUM_CLASSES * 4);
@@ -283,6 +291,41 @@ extern "C" int dj_profile_read(dj_engine* e, float* h_ms) {
     return DJ_OK;
 }
 
+static uint32_t scan_blocks(const dj_engine* e) {
+    uint64_t b = (e->t.mask + 1) / 256;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (uint32_t)b;
+}
+
+// ---- table hygiene ------------------------------------------------------------------------
+// Re-inserts the live barriers into the spare table and swaps: tombstones disappear, probe chains
+// shrink.  Synchronous (reads the live count back).  Outstanding continuations stay valid: their
+// slot hints are verified against the fingerprint before use.
+extern "C" int dj_compact(dj_engine* e, uint64_t* h_live) {
+    if (!e) return DJ_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const uint64_t slots = e->t.mask + 1;
+    Table to = e->t;
+    to.slots = e->slots_alt;
+    to.q = e->q_alt;
+    HIP_TRY(e, hipMemsetAsync(e->t.stat, 0, 4 * 8, e->stream));
+    rebuild_kernel<<<scan_blocks(e), 256, 0, e->stream>>>(e->t, to, e->t.stat);
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipMemsetAsync(e->t.slots, 0, slots * sizeof(Slot), e->stream));
+    HIP_TRY(e, hipMemsetAsync(e->t.q, 0xFF, slots * 8, e->stream));
+    unsigned long long live = 0;
+    HIP_TRY(e, hipMemcpyAsync(&live, e->t.stat, 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    e->slots_alt = e->t.slots;
+    e->q_alt = e->t.q;
+    e->t.slots = to.slots;
+    e->t.q = to.q;
+    e->used_upper = live;
+    if (h_live) *h_live = live;
+    return DJ_OK;
+}
+
 // ---- hot path ----------------------------------------------------------------------------
 extern "C" int dj_fork_batch(dj_engine* e, uint32_t n, const dj_fork_rec* d_recs, int32_t* d_status) {
     if (!e) return DJ_E_INVALID;
@@ -290,6 +333,13 @@ extern "C" int dj_fork_batch(dj_engine* e, uint32_t n, const dj_fork_rec* d_recs
     if (!d_recs || !d_status || !aligned16(d_recs)) return fail(e, DJ_E_INVALID, "fork: null or misaligned pointer");
     if (n > e->cfg.max_batch) return fail(e, DJ_E_TOO_LARGE, "fork: n=%u exceeds max_batch=%u", n, e->cfg.max_batch);
     HIP_TRY(e, hipSetDevice(e->cfg.device));
+    // every record may claim a never-used slot; past 80 % non-empty slots lookups of absent keys get
+    // long, so sweep the tombstones out first
+    if (e->used_upper + n > (e->t.mask + 1) / 5 * 4) {
+        int rc = dj_compact(e, nullptr);
+        if (rc != DJ_OK) return rc;
+    }
+    e->used_upper += n;
     LAUNCH(e, DJ_PROF_FORK_CLAIM, (fork_claim_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, d_recs, n, d_status)));
     LAUNCH(e, DJ_PROF_FORK_APPLY, (fork_apply_kernel<<<grid_for(n, FORK_APPLY_BLOCK), FORK_APPLY_BLOCK, 0, e->stream>>>(e->t, e->w, d_recs, n, d_status)));
     HIP_TRY(e, hipGetLastError());
@@ -329,13 +379,6 @@ extern "C" int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs
     else LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<64>(e, n, d_recs, d_payloads, pitch));
     HIP_TRY(e, hipGetLastError());
     return DJ_OK;
-}
-
-static uint32_t scan_blocks(const dj_engine* e) {
-    uint64_t b = (e->t.mask + 1) / 256;
-    if (b > 4096) b = 4096;
-    if (b < 1) b = 1;
-    return (uint32_t)b;
 }
 
 static uint32_t pop_blocks(const dj_engine* e) {

@@ -779,6 +779,28 @@ __global__ void store_in_queue_one_kernel(Table t, uint64_t lo, uint64_t hi, uin
     *err = 0;
 }
 
+// Table hygiene: deleted barriers leave tombstones, and a lookup of an absent key only stops at a
+// never-used slot.  rebuild re-inserts every live slot of `from` into the empty table `to`
+// (same size); the host then swaps the two and clears the old one.  live[0] += live slots.
+__global__ void __launch_bounds__(256) rebuild_kernel(Table from, Table to, unsigned long long* live) {
+    const uint64_t nslots = from.mask + 1;
+    unsigned long long mine = 0;
+    for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * blockDim.x) {
+        const Slot sl = from.slots[s];
+        if (sl.fp_lo < 2) continue;
+        bool created;
+        const int64_t d = find_or_claim(to, sl.fp_lo, sl.fp_hi, &created);
+        if (d < 0) continue;   // cannot happen: `to` has as many slots as `from` has live keys at most
+        Slot* dl = &to.slots[d];
+        dl->count = sl.count; dl->meta = sl.meta; dl->slab = sl.slab; dl->chain = 0;
+        dl->deadline = sl.deadline; dl->join_ts = sl.join_ts; dl->join_ts_read = sl.join_ts_read; dl->bits = sl.bits;
+        to.q[d] = from.q[s];
+        ++mine;
+    }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+    if (lane_id() == 0 && mine) a_add(live, mine);
+}
+
 __global__ void clamp_count_kernel(dj_sweep_result* res, uint32_t cap) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && res->n_conts > cap) res->n_conts = cap;
 }

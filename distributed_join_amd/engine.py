@@ -231,6 +231,12 @@ class Engine:
         self._check(self.L.dj_queue_scores(self.h, int(fp_lo), int(fp_hi), ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
+    def compact(self):
+        """Rehash the live barriers into the spare table (drops tombstones); returns the live count."""
+        live = ctypes.c_uint64(0)
+        self._check(self.L.dj_compact(self.h, ctypes.byref(live)))
+        return live.value
+
     def profile_enable(self, on=True):
         self._check(self.L.dj_profile_enable(self.h, 1 if on else 0))
 

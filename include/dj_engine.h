@@ -224,6 +224,12 @@ typedef struct dj_stats {
 } dj_stats;
 int dj_get_stats(dj_engine* e, dj_stats* h_stats);
 
+/* Table hygiene, no counterpart in the reference (Redis reclaims deleted keys itself): re-inserts
+ * the live barriers into a spare table so that the tombstones of deleted barriers stop lengthening
+ * lookups.  dj_fork_batch calls it by itself when the table may be more than 80 % non-empty;
+ * synchronous.  *h_live (optional) = live slots. */
+int dj_compact(dj_engine* e, uint64_t* h_live);
+
 /* ---- per-kernel timing (measurement aid; no counterpart in the reference) ---------- */
 /* Kernel ids for dj_profile_read.  With profiling enabled every launch of these kernels is
  * bracketed by a pair of HIP events on the engine's stream. */

@@ -287,3 +287,45 @@ def test_config5_shape_scaled(oracle_lib):
         d.check_all_snapshots(range(0, nb, 7))
     finally:
         e.close()
+
+
+def test_compaction_under_key_churn(oracle_lib):
+    """Unique barrier-ids keep arriving (every transaction has its own id), so deleted barriers pile
+    up as tombstones; the fork path compacts the table by itself.  State, in-flight continuations
+    (their slot hints go stale) and parity with the oracle must survive it."""
+    rng = np.random.default_rng(11)
+    rounds, per = 40, 100
+    ids = [f"churn{b:x}~tx{b:x}" for b in range(rounds * per)]
+    e = _engine(capacity_barriers=256, arena_bytes=16 << 20, max_count=4, payload_stride=64, max_batch=4096,
+                host_cap_conts=4096, host_cap_positions=16384)
+    o = oracle_lib.Oracle(ids, max_count=4, payload_stride=64)
+    d = ParityDriver(e, o, ids)
+    try:
+        assert e.stats()["slots"] == 1024
+        now, pending, compactions, last_tombs = T0, None, 0, 0
+        for r in range(rounds):
+            now += 10
+            fb = np.arange(r * per, (r + 1) * per)
+            d.fork(fb, np.full(per, 2), np.full(per, now + 25))      # the partial ones time out 2-3 rounds later
+            tombs = e.stats()["tombstones"]
+            if tombs < last_tombs:
+                compactions += 1
+            last_tombs = tombs
+            if pending is not None:                                   # acked after a possible compaction
+                d.ack(pending[0], pending[1], lambda k: k % 9 != 0, now + 1)
+            done = fb[:90]
+            jb = np.concatenate([done, done, fb[90:]])
+            jp = np.concatenate([np.zeros(90), np.ones(90), np.zeros(10)]).astype(np.int64)
+            order = rng.permutation(len(jb))
+            jb, jp = jb[order], jp[order]
+            d.join(jb, jp, np.full(len(jb), 64), np.zeros(len(jb), np.int64), payload_bytes(jb, jp, jb * 0, 64), now + 2)
+            pending = d.sweep(now + 3)
+            last_tombs = e.stats()["tombstones"]
+        d.ack(pending[0], pending[1], lambda k: True, now + 4)
+        assert compactions >= 2, "the table never compacted"
+        live = e.compact()
+        s = e.stats()
+        assert s["tombstones"] == 0 and s["live"] == live == o.live_barriers()
+        d.check_all_snapshots(range(0, len(ids), 13))
+    finally:
+        e.close()
