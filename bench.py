@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--payload", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--hot-frac", type=float, default=0.0,
+                    help="experiment: retarget this fraction of the joins to ONE barrier (hot key, replays)")
     ap.add_argument("--route", action="store_true",
                     help="run the multi-GPU routing path (partition + all-to-all) even with one rank")
     return ap.parse_args()
@@ -110,6 +112,9 @@ def main():
     g.manual_seed(1234 + rank)
     perm = torch.randperm(nb * c, device=dev, generator=g)
     b_of, p_of = perm // c, perm % c
+    if a.hot_frac > 0:
+        hot = torch.rand(nb * c, device=dev, generator=g) < a.hot_frac
+        b_of = torch.where(hot, torch.zeros_like(b_of), b_of)
     recs = torch.empty((nb * c, 4), dtype=torch.int64, device=dev)                 # dj_join_rec as 4 x i64
     recs[:, 0] = fps[b_of, 0]
     recs[:, 1] = fps[b_of, 1]
@@ -146,8 +151,13 @@ def main():
         router = Router(eng, dist.group.WORLD, max_send=batch, max_recv=max(recv_cap, nb * 2), pitch=pitch)
 
     now = [1_700_000_000_000]
+    pending = [None]     # routing handle of the NEXT batch, started while the current one is applied
 
-    def step(k):
+    def start_route(k):
+        lo = (k % steps_per_job) * batch
+        return router.start(recs[lo:lo + batch], payloads[lo:lo + batch], batch)
+
+    def step(k, prefetch=True):
         """One step: (fork at job start) + join batch + sweep + ack."""
         s = k % steps_per_job
         now[0] += 1
@@ -155,14 +165,18 @@ def main():
             if router is None:
                 eng.fork_batch_dev(nb, fork_recs, d_status)
             else:
-                r_recs, _, n_in = router.route(fork_recs, None, nb)
+                r_recs, _, n_in, h = router.route(fork_recs, None, nb)
                 eng.fork_batch_dev(n_in, r_recs, d_status)
+                router.release(h)
         lo = s * batch
         if router is None:
             eng.join_batch_dev(batch, recs[lo:lo + batch], payloads[lo:lo + batch], pitch, now[0], d_status)
         else:
-            r_recs, r_pay, n_in = router.route(recs[lo:lo + batch], payloads[lo:lo + batch], batch)
+            h = pending[0] if pending[0] is not None else start_route(k)
+            r_recs, r_pay, n_in = router.finish(h)
             eng.join_batch_dev(n_in, r_recs, r_pay, pitch, now[0], d_status)
+            router.release(h)
+            pending[0] = start_route(k + 1) if prefetch else None
         eng.sweep_dev(now[0], cap_conts, cap_pos, d_conts, d_lens, None, d_pay_out, d_res)
         eng.ack_batch_dev(cap_conts, d_res, d_conts, None, now[0], d_ack_status)
         with torch.cuda.stream(es):
@@ -180,7 +194,7 @@ def main():
     # warmup: whole jobs so the timed region starts at a job boundary with an empty table
     warm = (a.warmup + steps_per_job - 1) // steps_per_job * steps_per_job if a.warmup else 0
     for k in range(warm):
-        step(k)
+        step(k, prefetch=k + 1 < warm)
     barrier()
     fired_total.zero_()
     torch.cuda.synchronize()
@@ -190,7 +204,7 @@ def main():
     t0 = time.perf_counter()
     ev0.record(es)
     for k in range(a.steps):
-        step(k)
+        step(k, prefetch=k + 1 < a.steps)
     ev1.record(es)
     barrier()
     wall = time.perf_counter() - t0
@@ -210,13 +224,13 @@ def main():
         done = a.steps
         # finish the job in flight so the profiled job starts on an empty table
         while done % steps_per_job:
-            step(done)
+            step(done, prefetch=False)
             done += 1
         eng.sync()
         eng.profile_enable(True)
         acc = {}
         for k in range(steps_per_job):
-            step(k)
+            step(k, prefetch=False)
             for name, ms in eng.profile_read().items():
                 acc.setdefault(name, []).append(ms)
         eng.profile_enable(False)

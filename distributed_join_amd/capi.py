@@ -114,7 +114,7 @@ def load():
     L.dj_owner_of.restype = u32
     L.dj_owner_of.argtypes = [u64, u64, u32]
     L.dj_partition_joins.restype = i32
-    L.dj_partition_joins.argtypes = [vp, u32, u32, vp, vp, u64, vp, vp, vp, vp]
+    L.dj_partition_joins.argtypes = [vp, u32, u32, vp, vp, u64, vp, vp, vp, vp, vp]
     L.dj_compact.restype = i32
     L.dj_compact.argtypes = [vp, ctypes.POINTER(u64)]
     L.dj_profile_enable.restype = i32

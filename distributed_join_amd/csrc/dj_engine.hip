@@ -28,7 +28,8 @@ struct dj_engine {
     uint8_t* d_one_payload;
     int32_t* d_one_err;
     dj_sweep_result* d_result;   // internal result block when the caller passes none
-    uint32_t* d_part_counts;     // partition scratch: blocks * ranks
+    uint32_t* d_part_counts;     // partition scratch: blocks * ranks (engine stream)
+    uint32_t* d_part_counts2;    // same, for partitions launched on a caller stream
     void* allocs[64];
     int n_allocs;
     std::string err;
@@ -224,6 +225,7 @@ static int create_impl(dj_engine* e) {
     ALLOC(e, e->d_one_err, 4);
     ALLOC(e, e->d_result, sizeof(dj_sweep_result));
     ALLOC(e, e->d_part_counts, (size_t)grid_for(nb, PART_BLOCK) * PART_MAX_RANKS * 4);
+    ALLOC(e, e->d_part_counts2, (size_t)grid_for(nb, PART_BLOCK) * PART_MAX_RANKS * 4);
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return DJ_OK;
 }
@@ -555,16 +557,16 @@ extern "C" int dj_get_stats(dj_engine* e, dj_stats* h_stats) {
 
 // ---- multi-GPU routing ------------------------------------------------------------------
 template <int G>
-static void launch_gather_rows(dj_engine* e, const uint8_t* in, uint8_t* out, const uint32_t* origin, uint32_t n, uint64_t pitch) {
+static void launch_gather_rows(hipStream_t st, const uint8_t* in, uint8_t* out, const uint32_t* origin, uint32_t n, uint64_t pitch) {
     const uint64_t steps = ((uint64_t)n + (64 / G) - 1) / (64 / G);
     uint64_t blocks = (steps + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    gather_rows_kernel<G><<<(uint32_t)blocks, 256, 0, e->stream>>>(in, out, origin, n, pitch);
+    gather_rows_kernel<G><<<(uint32_t)blocks, 256, 0, st>>>(in, out, origin, n, pitch);
 }
 
 extern "C" int dj_partition_joins(dj_engine* e, uint32_t n, uint32_t n_ranks, const dj_join_rec* d_recs,
                                   const uint8_t* d_payloads, uint64_t pitch, dj_join_rec* d_recs_out,
-                                  uint8_t* d_payloads_out, uint32_t* d_origin, uint32_t* d_counts) {
+                                  uint8_t* d_payloads_out, uint32_t* d_origin, uint32_t* d_counts, void* stream) {
     if (!e) return DJ_E_INVALID;
     if (n_ranks < 1 || n_ranks > PART_MAX_RANKS) return fail(e, DJ_E_INVALID, "partition: n_ranks must be 1..%d", PART_MAX_RANKS);
     if (!d_recs || !d_recs_out || !d_origin || !d_counts) return fail(e, DJ_E_INVALID, "partition: null pointer");
@@ -573,21 +575,23 @@ extern "C" int dj_partition_joins(dj_engine* e, uint32_t n, uint32_t n_ranks, co
         return fail(e, DJ_E_INVALID, "partition: payload buffers must be 16-byte aligned, pitch a positive multiple of 16");
     if (n > e->cfg.max_batch) return fail(e, DJ_E_TOO_LARGE, "partition: n=%u exceeds max_batch=%u", n, e->cfg.max_batch);
     HIP_TRY(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    uint32_t* scratch = stream ? e->d_part_counts2 : e->d_part_counts;
     if (n == 0) {
-        HIP_TRY(e, hipMemsetAsync(d_counts, 0, n_ranks * 4, e->stream));
+        HIP_TRY(e, hipMemsetAsync(d_counts, 0, n_ranks * 4, st));
         return DJ_OK;
     }
     const uint32_t blocks = grid_for(n, PART_BLOCK);
-    partition_count_kernel<<<blocks, PART_BLOCK, 0, e->stream>>>(d_recs, n, n_ranks, e->d_part_counts);
-    partition_scan_kernel<<<1, 1024, 0, e->stream>>>(e->d_part_counts, blocks, n_ranks, d_counts);
-    partition_scatter_kernel<<<blocks, PART_BLOCK, 0, e->stream>>>(d_recs, n, n_ranks, e->d_part_counts, d_recs_out, d_origin);
+    partition_count_kernel<<<blocks, PART_BLOCK, 0, st>>>(d_recs, n, n_ranks, scratch);
+    partition_scan_kernel<<<1, 1024, 0, st>>>(scratch, blocks, n_ranks, d_counts);
+    partition_scatter_kernel<<<blocks, PART_BLOCK, 0, st>>>(d_recs, n, n_ranks, scratch, d_recs_out, d_origin);
     if (d_payloads) {
         const uint64_t lanes = pitch / 16;
-        if (lanes <= 4) launch_gather_rows<4>(e, d_payloads, d_payloads_out, d_origin, n, pitch);
-        else if (lanes <= 8) launch_gather_rows<8>(e, d_payloads, d_payloads_out, d_origin, n, pitch);
-        else if (lanes <= 16) launch_gather_rows<16>(e, d_payloads, d_payloads_out, d_origin, n, pitch);
-        else if (lanes <= 32) launch_gather_rows<32>(e, d_payloads, d_payloads_out, d_origin, n, pitch);
-        else launch_gather_rows<64>(e, d_payloads, d_payloads_out, d_origin, n, pitch);
+        if (lanes <= 4) launch_gather_rows<4>(st, d_payloads, d_payloads_out, d_origin, n, pitch);
+        else if (lanes <= 8) launch_gather_rows<8>(st, d_payloads, d_payloads_out, d_origin, n, pitch);
+        else if (lanes <= 16) launch_gather_rows<16>(st, d_payloads, d_payloads_out, d_origin, n, pitch);
+        else if (lanes <= 32) launch_gather_rows<32>(st, d_payloads, d_payloads_out, d_origin, n, pitch);
+        else launch_gather_rows<64>(st, d_payloads, d_payloads_out, d_origin, n, pitch);
     }
     HIP_TRY(e, hipGetLastError());
     return DJ_OK;

@@ -126,12 +126,13 @@ class Engine:
                                       d_result.data_ptr() if d_result is not None else None,
                                       h_result.ctypes.data_as(ctypes.c_void_p) if h_result is not None else None))
 
-    def partition_joins_dev(self, n, n_ranks, d_recs, d_payloads, pitch, d_recs_out, d_payloads_out, d_origin, d_counts):
+    def partition_joins_dev(self, n, n_ranks, d_recs, d_payloads, pitch, d_recs_out, d_payloads_out, d_origin, d_counts,
+                            stream_ptr=None):
         self._check(self.L.dj_partition_joins(self.h, int(n), int(n_ranks), d_recs.data_ptr(),
                                               d_payloads.data_ptr() if d_payloads is not None else None, int(pitch),
                                               d_recs_out.data_ptr(),
                                               d_payloads_out.data_ptr() if d_payloads_out is not None else None,
-                                              d_origin.data_ptr(), d_counts.data_ptr()))
+                                              d_origin.data_ptr(), d_counts.data_ptr(), stream_ptr))
 
     # ---- host layer (numpy in, numpy out, synchronous) -----------------------------------------
     def _bufs(self):

@@ -5,9 +5,18 @@ The reference has no counterpart (its replicas share one Redis, reference
 src/distributed_join/redis.clj:13-15); the exchange is the only collective on the path —
 sweeps, gathers, acks and recovers are GPU-local.
 
-route() = partition (HIP kernels, dj_partition_joins: stable, so every owner sees the
-events of one source in array order) + counts exchange + two all_to_all_single calls
-(records, messages).  The receiver's order is: source rank 0's events, then rank 1's, ...
+route = partition (HIP kernels, dj_partition_joins: stable, so every owner sees the events of
+one source in array order) + counts exchange + two all_to_all_single calls (records,
+messages).  The receiver's order is: source rank 0's events, then rank 1's, ...
+
+The router works on its OWN stream with two buffer sets, so the routing of batch k+1 (its
+kernels, its collectives and the host's waits for the bucket sizes) runs while the engine's
+stream applies batch k:
+    h = router.start(recs, payloads, n)     # partition + exchange, asynchronous
+    ...                                      # the engine applies the previous batch
+    recs_in, pay_in, n_in = router.finish(h) # the engine's stream waits for the data (no host wait)
+    engine.join_batch_dev(n_in, recs_in, pay_in, ...)
+    router.release(h)                        # after the batch's kernels are queued: buffers may be reused
 """
 import numpy as np
 
@@ -38,32 +47,73 @@ def exchange(dist, group, recs_sorted, pay_sorted, send_counts, recv_recs, recv_
     return n_in, recv_counts
 
 
+class _Slot:
+    """One of the two buffer sets."""
+
+    def __init__(self, torch, dev, max_send, max_recv, pitch):
+        self.recs_sorted = torch.empty((max_send, 4), dtype=torch.int64, device=dev)
+        self.pay_sorted = torch.empty((max_send, pitch), dtype=torch.uint8, device=dev)
+        self.origin = torch.empty(max_send, dtype=torch.int32, device=dev)
+        self.counts = torch.empty(64, dtype=torch.int32, device=dev)
+        self.recv_recs = torch.empty((max_recv, 4), dtype=torch.int64, device=dev)
+        self.recv_pay = torch.empty((max_recv, pitch), dtype=torch.uint8, device=dev)
+        self.ready = torch.cuda.Event()      # data has arrived (recorded on the router's stream)
+        self.free = torch.cuda.Event()       # the engine has consumed it (recorded on the engine's stream)
+        self.free_pending = False
+        self.n_in = 0
+        self.has_pay = False
+
+
 class Router:
     def __init__(self, engine, group, max_send, max_recv, pitch):
         import torch
         import torch.distributed as dist
+        self.torch = torch
         self.e, self.group, self.dist = engine, group, dist
         self.world = dist.get_world_size(group)
         self.pitch = int(pitch)
         dev = engine.device
-        self.recs_sorted = torch.empty((max_send, 4), dtype=torch.int64, device=dev)
-        self.pay_sorted = torch.empty((max_send, self.pitch), dtype=torch.uint8, device=dev)
-        self.origin = torch.empty(max_send, dtype=torch.int32, device=dev)
-        self.counts = torch.empty(64, dtype=torch.int32, device=dev)
-        self.recv_recs = torch.empty((max_recv, 4), dtype=torch.int64, device=dev)
-        self.recv_pay = torch.empty((max_recv, self.pitch), dtype=torch.uint8, device=dev)
+        self.stream = torch.cuda.Stream(device=dev)
+        self.engine_stream = engine.torch_stream()
+        self.slots = [_Slot(torch, dev, max_send, max_recv, self.pitch) for _ in range(2)]
+        self.turn = 0
+
+    def start(self, d_recs, d_payloads, n):
+        """Begin routing n records (rows of the (n, 4) int64 tensor d_recs: dj_join_rec or dj_fork_rec)
+        with their messages ((n, pitch) uint8, or None).  The inputs must already be complete on the
+        device.  Returns a handle for finish()."""
+        torch = self.torch
+        s = self.slots[self.turn]
+        self.turn ^= 1
+        with torch.cuda.stream(self.stream):
+            if s.free_pending:                    # the engine may still be reading this buffer set
+                self.stream.wait_event(s.free)
+                s.free_pending = False
+            s.has_pay = d_payloads is not None
+            self.e.partition_joins_dev(n, self.world, d_recs, d_payloads, self.pitch, s.recs_sorted,
+                                       s.pay_sorted if s.has_pay else None, s.origin, s.counts,
+                                       stream_ptr=self.stream.cuda_stream)
+            send_counts = [int(x) for x in s.counts[:self.world].cpu().tolist()]   # waits for the router's stream only
+            s.n_in, _ = exchange(self.dist, self.group, s.recs_sorted, s.pay_sorted if s.has_pay else None,
+                                 send_counts, s.recv_recs, s.recv_pay)
+            s.ready.record(self.stream)
+        return s
+
+    def finish(self, s):
+        """-> (records for this rank, messages for this rank or None, n_received).  The engine's stream
+        waits for the exchange; the host does not."""
+        self.engine_stream.wait_event(s.ready)
+        return s.recv_recs, (s.recv_pay if s.has_pay else None), s.n_in
+
+    def release(self, s):
+        """Call after the kernels that read the routed batch have been queued on the engine's stream."""
+        s.free.record(self.engine_stream)
+        s.free_pending = True
 
     def route(self, d_recs, d_payloads, n):
-        """d_recs: (n, 4) int64 rows = 32-byte records whose first 16 bytes are the fingerprint
-        (dj_join_rec or dj_fork_rec); d_payloads: (n, pitch) uint8 or None.
-        -> (records for this rank, messages for this rank, n_received)."""
-        import torch
-        torch.cuda.current_stream().synchronize()
-        self.e.partition_joins_dev(n, self.world, d_recs, d_payloads, self.pitch, self.recs_sorted,
-                                   self.pay_sorted if d_payloads is not None else None, self.origin, self.counts)
-        self.e.sync()
-        send_counts = [int(x) for x in self.counts[:self.world].cpu().tolist()]
-        n_in, _ = exchange(self.dist, self.group, self.recs_sorted, self.pay_sorted if d_payloads is not None else None,
-                           send_counts, self.recv_recs, self.recv_pay)
-        torch.cuda.current_stream().synchronize()
-        return self.recv_recs, (self.recv_pay if d_payloads is not None else None), n_in
+        """start + finish in one call (no overlap).  The caller releases nothing: the next start() on
+        this buffer set waits for the engine's stream as it is now."""
+        self.torch.cuda.current_stream().synchronize()
+        s = self.start(d_recs, d_payloads, n)
+        out = self.finish(s)
+        return out + (s,)

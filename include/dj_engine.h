@@ -251,11 +251,15 @@ uint32_t dj_owner_of(uint64_t fp_lo, uint64_t fp_hi, uint32_t n_ranks);
 /* Stable partition of n join events by owner rank: d_counts[r] = events owned by r;
  * d_recs_out / d_payloads_out hold the events grouped by rank in array order inside each
  * group; d_origin[j] = input index of output event j (to route statuses back).
- * The exchange itself (all-to-all-v) is the caller's collective. */
+ * The exchange itself (all-to-all-v) is the caller's collective.  Any 32-byte record whose
+ * first 16 bytes are the fingerprint can be routed (dj_fork_rec too); d_payloads may be NULL.
+ * stream: hipStream_t to launch on, NULL = the engine's stream.  The partition reads no barrier
+ * state, so a router may run it on its own stream while the engine applies the previous batch
+ * (one partition in flight per stream). */
 int dj_partition_joins(dj_engine* e, uint32_t n, uint32_t n_ranks,
                        const dj_join_rec* d_recs, const uint8_t* d_payloads, uint64_t pitch,
                        dj_join_rec* d_recs_out, uint8_t* d_payloads_out,
-                       uint32_t* d_origin, uint32_t* d_counts);
+                       uint32_t* d_origin, uint32_t* d_counts, void* stream);
 
 #ifdef __cplusplus
 }

@@ -222,11 +222,28 @@ def test_router_single_rank_roundtrip():
         recs = torch.from_numpy(rng.integers(2, 1 << 62, (n, 4), dtype=np.int64)).to(e.device)
         pay = torch.from_numpy(rng.integers(0, 256, (n, pitch), dtype=np.uint8)).to(e.device)
         r = Router(e, dist.group.WORLD, max_send=n, max_recv=n, pitch=pitch)
-        rr, rp, n_in = r.route(recs, pay, n)
+        rr, rp, n_in, h = r.route(recs, pay, n)
+        e.sync()
+        torch.cuda.synchronize()
         assert n_in == n
         assert torch.equal(rr[:n], recs) and torch.equal(rp[:n], pay)
-        rr, rp, n_in = r.route(recs[:1000], None, 1000)
-        assert n_in == 1000 and rp is None and torch.equal(rr[:1000], recs[:1000])
+        r.release(h)
+        # overlapped form: two batches in flight on the router's own stream
+        h1 = r.start(recs[:1000], None, 1000)
+        h2 = r.start(recs[1000:3000], pay[1000:3000], 2000)
+        rr1, rp1, n1 = r.finish(h1)
+        rr2, rp2, n2 = r.finish(h2)
+        e.sync()
+        torch.cuda.synchronize()
+        assert n1 == 1000 and rp1 is None and torch.equal(rr1[:1000], recs[:1000])
+        assert n2 == 2000 and torch.equal(rr2[:2000], recs[1000:3000]) and torch.equal(rp2[:2000], pay[1000:3000])
+        r.release(h1)
+        r.release(h2)
+        h3 = r.start(recs[:500], pay[:500], 500)          # reuses the first buffer set after its release
+        rr3, rp3, n3 = r.finish(h3)
+        e.sync()
+        torch.cuda.synchronize()
+        assert n3 == 500 and torch.equal(rr3[:500], recs[:500]) and torch.equal(rp3[:500], pay[:500])
     finally:
         dist.destroy_process_group()
         e.close()
