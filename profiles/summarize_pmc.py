@@ -14,9 +14,6 @@ import csv
 import json
 import sys
 
-ALIASES = {"join_copy_kernel<4>": "join_copy", "join_copy_kernel<8>": "join_copy", "join_copy_kernel<16>": "join_copy",
-           "join_copy_kernel<32>": "join_copy", "join_copy_kernel<64>": "join_copy"}
-
 
 def per_kernel(path):
     acc = collections.defaultdict(list)
@@ -24,8 +21,8 @@ def per_kernel(path):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "")
         if not name.startswith("dj::"):
             continue
-        name = name[4:]
-        name = ALIASES.get(name, name.replace("_kernel", ""))
+        name = name[4:].split("<")[0]
+        name = name.replace("_kernel", "")
         name = {"join_resolve_complex": "join_complex", "pop_due": "pop"}.get(name, name)
         acc[name].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
