@@ -113,8 +113,10 @@ def main():
     perm = torch.randperm(nb * c, device=dev, generator=g)
     b_of, p_of = perm // c, perm % c
     if a.hot_frac > 0:
+        # barrier 0 is the hot key: it keeps receiving replays of positions 0..c-2 and never completes
         hot = torch.rand(nb * c, device=dev, generator=g) < a.hot_frac
         b_of = torch.where(hot, torch.zeros_like(b_of), b_of)
+        p_of = torch.where(b_of == 0, p_of % (c - 1), p_of)
     recs = torch.empty((nb * c, 4), dtype=torch.int64, device=dev)                 # dj_join_rec as 4 x i64
     recs[:, 0] = fps[b_of, 0]
     recs[:, 1] = fps[b_of, 1]
@@ -181,6 +183,9 @@ def main():
         eng.ack_batch_dev(cap_conts, d_res, d_conts, None, now[0], d_ack_status)
         with torch.cuda.stream(es):
             fired_total.add_(d_res[:4].view(torch.int32)[0].to(torch.int64))
+        if a.hot_frac > 0:
+            eng.sync()      # a host that reads each batch's statuses; also lets the engine see the previous
+                            # batch's longest chain in time to pick the parallel hot-barrier kernels
 
     def barrier():
         eng.sync()

@@ -35,6 +35,7 @@ constexpr uint64_t NQ = DJ_NOT_QUEUED;
 constexpr uint64_t Q_NONE = ~0ull;          // in neither queue
 constexpr uint64_t Q_POPPED = 1ull << 63;   // removed from the primary queue, still in the backup queue
 constexpr uint32_t META_HAS = 1u;      // metadata key exists
+constexpr uint32_t META_HOT = 2u;      // hint: the barrier received hundreds of events in its last batch
 constexpr uint32_t RETRY_NIL = 0xFFu;  // retry counter absent
 constexpr int NUM_CLASSES = 11;        // 1, 2, 4 ... 1024 positions
 constexpr uint64_t NODST = ~0ull;
@@ -113,8 +114,21 @@ struct Work {
     unsigned int* counters_next;  // the other bank: zeroed by the current batch for the next one
     unsigned long long* sweep;    // S_* below, bank of the current sweep
     unsigned long long* sweep_next;
+    // hot-barrier path (barriers with long chains), see the cx_* kernels
+    uint32_t* cx_keys;            // [CX_HASH] slab of a hot barrier, 0 = empty
+    uint32_t* cx_val;             // [CX_HASH] its index in complex_[]
+    uint32_t* cx_fmin;            // [CX_CAP][1024] first event index per position
+    uint32_t* cx_fmax;            // [CX_CAP][1024] last event index + 1 per position
+    unsigned long long* cx_atmin; // [CX_CAP] smallest now + 1000 * max-wait among the barrier's events
+    uint32_t* cx_cnt;             // [CX_CAP] events of the barrier in this batch
+    uint32_t* cx_T;               // [CX_CAP] first event index that answers COMPLETE, IDX_NONE = none
+    uint32_t* cx_nq;              // [CX_CAP] 1 when the barrier was not in the primary queue before the batch
+    uint32_t cx_on;               // 1: this batch runs the parallel hot-barrier kernels
 };
-enum { C_TOUCHED = 0, C_COMPLEX = 1, C_COUNT = 8 };
+enum { C_TOUCHED = 0, C_COMPLEX = 1, C_MAXCHAIN = 2, C_COUNT = 8 };
+constexpr uint32_t CX_CAP = 4096;     // hot barriers per batch handled by the parallel path
+constexpr uint32_t CX_HASH = 16384;   // power of two, >= 2 * CX_CAP
+constexpr uint32_t IDX_NONE = 0xFFFFFFFFu;
 // sweep scratch: S_CURSOR packs both output cursors so a block takes its output range with one
 // atomic: continuations in the low 31 bits, positions above (positions * 64 B <= arena <= 256 GiB)
 enum { S_CURSOR = 0, S_MORE = 1, S_COUNT = 2 };

@@ -36,6 +36,8 @@ struct dj_engine {
     // optional per-kernel timing (dj_profile_enable): one event pair per kernel id
     Slot* slots_alt;             // second table for dj_compact (always all-empty between calls)
     uint64_t* q_alt;
+    int cx_force;                // -1: automatic, 0 / 1: force the serial / parallel hot-barrier kernels (tests)
+    unsigned int* h_maxchain;    // pinned: longest chain of the previous join batch (picks the hot-barrier kernels)
     uint64_t used_upper;         // upper bound of non-empty slots (live + tombstones) since the last compaction
     int ctr_bank, sweep_bank;    // which half of the double-banked scratch the next call uses
     unsigned int* d_counters;    // 2 x C_COUNT
@@ -148,6 +150,7 @@ extern "C" void dj_destroy(dj_engine* e) {
         if (e->ev_stop[k]) (void)hipEventDestroy(e->ev_stop[k]);
     }
     for (int i = 0; i < e->n_allocs; ++i) (void)hipFree(e->allocs[i]);
+    if (e->h_maxchain) (void)hipHostFree(e->h_maxchain);
     delete e;
 }
 
@@ -209,6 +212,17 @@ static int create_impl(dj_engine* e) {
     ALLOC(e, w.cont_slot, (nb > slots ? nb : slots) * 4);
     ALLOC(e, e->d_counters, 2 * C_COUNT * 4);
     HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 2 * C_COUNT * 4, e->stream));
+    ALLOC(e, w.cx_keys, CX_HASH * 4);
+    ALLOC(e, w.cx_val, CX_HASH * 4);
+    ALLOC(e, w.cx_fmin, (size_t)CX_CAP * 1024 * 4);
+    ALLOC(e, w.cx_fmax, (size_t)CX_CAP * 1024 * 4);
+    ALLOC(e, w.cx_atmin, CX_CAP * 8);
+    ALLOC(e, w.cx_cnt, CX_CAP * 4);
+    ALLOC(e, w.cx_T, CX_CAP * 4);
+    ALLOC(e, w.cx_nq, CX_CAP * 4);
+    w.cx_on = 0;
+    HIP_TRY(e, hipHostMalloc((void**)&e->h_maxchain, 64, hipHostMallocDefault));
+    *e->h_maxchain = 0;
     ALLOC(e, e->d_sweep, 2 * S_COUNT * 8);
     HIP_TRY(e, hipMemsetAsync(e->d_sweep, 0, 2 * S_COUNT * 8, e->stream));
     e->ctr_bank = e->sweep_bank = 0;
@@ -248,6 +262,8 @@ extern "C" int dj_create(const dj_config* cfg, dj_engine** out) {
     e->n_allocs = 0;
     e->stream = nullptr;
     e->profiling = 0;
+    e->h_maxchain = nullptr;
+    e->cx_force = -1;
     for (int k = 0; k < DJ_PROF_KERNELS; ++k) { e->ev_start[k] = nullptr; e->ev_stop[k] = nullptr; e->ev_used[k] = 0; }
     int rc = create_impl(e);
     if (rc != DJ_OK) {
@@ -267,6 +283,12 @@ extern "C" int dj_sync(dj_engine* e) {
 }
 
 extern "C" void* dj_stream(dj_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+extern "C" int dj_set_hot_path(dj_engine* e, int mode) {
+    if (!e || mode < -1 || mode > 1) return DJ_E_INVALID;
+    e->cx_force = mode;
+    return DJ_OK;
+}
 
 extern "C" int dj_profile_enable(dj_engine* e, int on) {
     if (!e) return DJ_E_INVALID;
@@ -349,11 +371,12 @@ extern "C" int dj_fork_batch(dj_engine* e, uint32_t n, const dj_fork_rec* d_recs
 }
 
 template <int G>
-static void launch_join_copy(dj_engine* e, uint32_t n, const dj_join_rec* recs, const uint8_t* payloads, uint64_t pitch) {
+static void launch_join_copy(dj_engine* e, uint32_t n, const dj_join_rec* recs, const uint8_t* payloads, uint64_t pitch,
+                             int32_t* status) {
     const uint64_t steps = ((uint64_t)n + (64 / G) - 1) / (64 / G);          // wave steps
     uint64_t blocks = (steps + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    join_copy_kernel<G><<<(uint32_t)blocks, 256, 0, e->stream>>>(e->t, e->w, recs, payloads, pitch, n);
+    join_copy_kernel<G><<<(uint32_t)blocks, 256, 0, e->stream>>>(e->t, e->w, recs, payloads, pitch, n, status);
 }
 
 extern "C" int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs, const uint8_t* d_payloads,
@@ -370,15 +393,31 @@ extern "C" int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs
     e->w.counters = e->d_counters + e->ctr_bank * C_COUNT;
     e->w.counters_next = e->d_counters + (e->ctr_bank ^ 1) * C_COUNT;
     e->ctr_bank ^= 1;
+    e->w.cx_on = e->cx_force >= 0 ? (uint32_t)e->cx_force : (*(volatile unsigned int*)e->h_maxchain >= 256 ? 1u : 0u);
     LAUNCH(e, DJ_PROF_JOIN_LINK, (join_link_kernel<<<grid_for(n, LINK_BLOCK), LINK_BLOCK, 0, e->stream>>>(e->t, e->w, d_recs, n, pitch, d_status)));
     LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, now_ms, d_status)));
-    LAUNCH(e, DJ_PROF_JOIN_COMPLEX, (join_resolve_complex_kernel<<<256, 64, 0, e->stream>>>(e->t, e->w, now_ms, d_status)));
+    // Long chains (hot barriers): the previous batch's longest chain, read back without waiting, picks
+    // between the serial kernel and the parallel cx_* kernels.  Both give the same results.
+    if (e->w.cx_on) {
+        HIP_TRY(e, hipMemsetAsync(e->w.cx_keys, 0, CX_HASH * 4, e->stream));
+        if (e->profiling) (void)hipEventRecord(e->ev_start[DJ_PROF_JOIN_COMPLEX], e->stream);
+        cx_init_kernel<<<256, 64, 0, e->stream>>>(e->t, e->w);
+        uint32_t sb = grid_for(n, 256);
+        if (sb > 4096) sb = 4096;
+        cx_scan_kernel<<<sb, 256, 0, e->stream>>>(e->w, n, now_ms);
+        cx_finalize_kernel<<<256, 64, 0, e->stream>>>(e->t, e->w, now_ms);
+        join_resolve_complex_kernel<<<256, 64, 0, e->stream>>>(e->t, e->w, now_ms, d_status);
+        if (e->profiling) { (void)hipEventRecord(e->ev_stop[DJ_PROF_JOIN_COMPLEX], e->stream); e->ev_used[DJ_PROF_JOIN_COMPLEX] = 1; }
+    } else {
+        LAUNCH(e, DJ_PROF_JOIN_COMPLEX, (join_resolve_complex_kernel<<<256, 64, 0, e->stream>>>(e->t, e->w, now_ms, d_status)));
+    }
     const uint32_t lanes = e->cfg.payload_stride / 16;
-    if (lanes <= 4) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<4>(e, n, d_recs, d_payloads, pitch));
-    else if (lanes <= 8) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<8>(e, n, d_recs, d_payloads, pitch));
-    else if (lanes <= 16) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<16>(e, n, d_recs, d_payloads, pitch));
-    else if (lanes <= 32) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<32>(e, n, d_recs, d_payloads, pitch));
-    else LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<64>(e, n, d_recs, d_payloads, pitch));
+    if (lanes <= 4) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<4>(e, n, d_recs, d_payloads, pitch, d_status));
+    else if (lanes <= 8) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<8>(e, n, d_recs, d_payloads, pitch, d_status));
+    else if (lanes <= 16) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<16>(e, n, d_recs, d_payloads, pitch, d_status));
+    else if (lanes <= 32) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<32>(e, n, d_recs, d_payloads, pitch, d_status));
+    else LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<64>(e, n, d_recs, d_payloads, pitch, d_status));
+    HIP_TRY(e, hipMemcpyAsync(e->h_maxchain, &e->w.counters[C_MAXCHAIN], 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipGetLastError());
     return DJ_OK;
 }

@@ -128,9 +128,21 @@ constexpr int LINK_BLOCK = 1024;
 __global__ void __launch_bounds__(LINK_BLOCK) join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n,
                                                                uint64_t pitch, int32_t* status) {
     __shared__ uint32_t lds[17];
+    // Block-level pre-aggregation for barriers flagged hot: their events are chained inside the block
+    // through LDS and the block issues ONE exchange per hot barrier (a contended returning atomic
+    // costs ~60 ns, ten thousand of them on one word would serialise the whole pass).
+    constexpr int HOT_KEYS = 8, HOT_LIST = 128;
+    __shared__ uint32_t hot_key[HOT_KEYS];               // slot + 1, 0 = free
+    __shared__ uint32_t hot_cnt[HOT_KEYS];
+    __shared__ uint32_t hot_list[HOT_KEYS][HOT_LIST];    // event index + 1
+    __shared__ uint32_t hot_prev[HOT_KEYS];
+    if (threadIdx.x < HOT_KEYS) { hot_key[threadIdx.x] = 0; hot_cnt[threadIdx.x] = 0; }
+    __syncthreads();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool first = false;
     uint32_t slot = 0;
+    int agg_key = -1;
+    uint32_t agg_rank = 0, agg_pos = 0, agg_mw = 0;
     if (i < n) {
         const ulonglong2 a = reinterpret_cast<const ulonglong2*>(recs)[2 * (size_t)i];
         const uint4 b = reinterpret_cast<const uint4*>(recs)[2 * (size_t)i + 1];  // position, len, max_wait, -
@@ -151,11 +163,38 @@ __global__ void __launch_bounds__(LINK_BLOCK) join_link_kernel(Table t, Work w, 
             // exceptions (COMPLETE / NEAREST_NOT_QUEUED statuses, superseded messages)
             status[i] = DJ_JOIN_WAITING;
             w.dst[i] = dst_pack(t.slots[s].slab, t.slots[s].count);
-            uint32_t prev = a_xchg(&t.slots[s].chain, i + 1);
-            w.node[i] = node_pack(prev, b.x, b.z);
-            first = prev == 0;
             slot = (uint32_t)s;
+            if (t.slots[s].meta & META_HOT) {
+                for (int j = 0; j < HOT_KEYS && agg_key < 0; ++j) {
+                    const uint32_t k = atomicCAS(&hot_key[j], 0u, slot + 1);
+                    if (k == 0 || k == slot + 1) {
+                        const uint32_t r = atomicAdd(&hot_cnt[j], 1u);
+                        if (r < HOT_LIST) {
+                            hot_list[j][r] = i + 1;
+                            agg_key = j; agg_rank = r; agg_pos = b.x; agg_mw = b.z;
+                        }
+                        break;       // list full: fall through to the direct exchange
+                    }
+                }
+            }
+            if (agg_key < 0) {
+                const uint32_t prev = a_xchg(&t.slots[s].chain, i + 1);
+                w.node[i] = node_pack(prev, b.x, b.z);
+                first = prev == 0;
+            }
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < HOT_KEYS && hot_cnt[threadIdx.x] != 0) {
+        const uint32_t m = hot_cnt[threadIdx.x] < HOT_LIST ? hot_cnt[threadIdx.x] : HOT_LIST;
+        hot_prev[threadIdx.x] = a_xchg(&t.slots[hot_key[threadIdx.x] - 1].chain, hot_list[threadIdx.x][m - 1]);
+    }
+    __syncthreads();
+    if (agg_key >= 0) {
+        // element r links to element r-1 of its block-local list, element 0 to the chain as it was
+        const uint32_t next = agg_rank == 0 ? hot_prev[agg_key] : hot_list[agg_key][agg_rank - 1];
+        w.node[i] = node_pack(next, agg_pos, agg_mw);
+        first = agg_rank == 0 && next == 0;
     }
     uint32_t at = block_append(&w.counters[C_TOUCHED], first, lds);
     if (first) w.touched[at] = slot;
@@ -253,6 +292,7 @@ __global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint
             sl->bits = count > 64 ? (uint64_t)r.arrived : r.bits;
             sl->join_ts = now;                              // SET <id>:join-ts, redis.clj:136
             sl->chain = 0;
+            if (sl->meta & META_HOT) sl->meta &= ~META_HOT; // a short chain: not hot any more
             if (r.enq) t.q[s] = now;                    // ZADD both at now, redis.clj:257-258
             else if (r.pa_dirty) t.q[s] = r.pa;         // ZADD both at the nearer date, redis.clj:270-271
         }
@@ -266,14 +306,14 @@ __global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint
 // position: the barrier completes at T = max over newly present positions of the first
 // index touching it; events at or after T answer COMPLETE, the message of a position comes
 // from its last index.
-constexpr uint32_t IDX_NONE = 0xFFFFFFFFu;
-
+// This kernel is the serial form: lane 0 walks the chain.  It handles every long chain when the
+// parallel kernels below are off, and the barriers beyond CX_CAP when they are on.
 __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work w, uint64_t now, int32_t* status) {
     __shared__ uint32_t fmin[1024];
     __shared__ uint32_t fmax[1024];
     const uint32_t lane = threadIdx.x;
     const uint32_t nc = w.counters[C_COMPLEX];
-    for (uint32_t c = blockIdx.x; c < nc; c += gridDim.x) {
+    for (uint32_t c = blockIdx.x + (w.cx_on ? CX_CAP : 0); c < nc; c += gridDim.x) {
         const uint32_t s = w.complex_[c];
         Slot* sl = &t.slots[s];
         const uint32_t count = sl->count, slab = sl->slab;
@@ -282,13 +322,16 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
         __syncthreads();
         uint64_t at_min = NQ;      // smallest now + 1000*max-wait over the batch's waiting events
         if (lane == 0) {
-            for (uint32_t cur = head; cur != 0;) {
+            uint32_t len = 0;
+            for (uint32_t cur = head; cur != 0; ++len) {
                 const uint64_t x = w.node[cur - 1];
                 const uint32_t i = cur - 1, pos = node_pos(x);
                 if (i < fmin[pos]) fmin[pos] = i;
                 if (i + 1 > fmax[pos]) fmax[pos] = i + 1;
                 cur = node_next(x);
             }
+            a_max(&w.counters[C_MAXCHAIN], len);    // the host picks the parallel kernels for the next batch from this
+            if (len >= 256) sl->meta |= META_HOT; else sl->meta &= ~META_HOT;
         }
         __syncthreads();
         // newly present positions, word by word (lane j owns words j, j+64, ...)
@@ -349,11 +392,122 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
     }
 }
 
+// ---- parallel form for hot barriers ----------------------------------------------------------
+// A chain of thousands of events (one hot barrier, at-least-once replays) is too long to walk with
+// one lane.  Instead: cx_init registers the hot barriers in a small hash keyed by slab;
+// cx_scan lets EVERY event of the batch look its barrier up there and fold its index into the
+// per-position first / last tables with atomics; cx_finalize (one wave per hot barrier) derives
+// the completion index T and updates the barrier; the copy pass then answers the hot barriers'
+// events from T and the last-writer table.  Same results as the serial kernel.
+
+__device__ inline uint32_t cx_hash(uint32_t slab) { return (slab * 2654435761u) & (CX_HASH - 1); }
+
+__device__ inline uint32_t cx_lookup(const Work& w, uint32_t slab) {
+    for (uint32_t h = cx_hash(slab);; h = (h + 1) & (CX_HASH - 1)) {
+        const uint32_t k = w.cx_keys[h];
+        if (k == slab) return w.cx_val[h];
+        if (k == 0) return IDX_NONE;
+    }
+}
+
+__global__ void __launch_bounds__(64) cx_init_kernel(Table t, Work w) {
+    const uint32_t nc = min(w.counters[C_COMPLEX], CX_CAP);
+    for (uint32_t c = blockIdx.x; c < nc; c += gridDim.x) {
+        const Slot* sl = &t.slots[w.complex_[c]];
+        const uint32_t count = sl->count;
+        for (uint32_t p = threadIdx.x; p < count; p += 64) {
+            w.cx_fmin[c * 1024 + p] = IDX_NONE;
+            w.cx_fmax[c * 1024 + p] = 0;
+        }
+        if (threadIdx.x == 0) {
+            w.cx_atmin[c] = NQ;
+            w.cx_cnt[c] = 0;
+            const uint32_t slab = sl->slab;        // unique per barrier, never 0 for a joinable barrier
+            for (uint32_t h = cx_hash(slab);; h = (h + 1) & (CX_HASH - 1)) {
+                if (atomicCAS(&w.cx_keys[h], 0u, slab) == 0u) { w.cx_val[h] = c; break; }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) cx_scan_kernel(Work w, uint32_t n, uint64_t now) {
+    if (w.counters[C_COMPLEX] == 0) return;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t d = w.dst[i];
+        if (d == NODST) continue;
+        const uint32_t c = cx_lookup(w, (uint32_t)d);
+        if (c == IDX_NONE) continue;
+        const uint64_t x = w.node[i];
+        const uint32_t pos = node_pos(x), mw = node_mw(x);
+        atomicMin(&w.cx_fmin[c * 1024 + pos], (uint32_t)i);
+        atomicMax(&w.cx_fmax[c * 1024 + pos], (uint32_t)i + 1);
+        atomicAdd(&w.cx_cnt[c], 1u);
+        if (mw) atomicMin(&w.cx_atmin[c], (unsigned long long)(now + 1000ull * mw));
+    }
+}
+
+__global__ void __launch_bounds__(64) cx_finalize_kernel(Table t, Work w, uint64_t now) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t nc = min(w.counters[C_COMPLEX], CX_CAP);
+    for (uint32_t c = blockIdx.x; c < nc; c += gridDim.x) {
+        const uint32_t s = w.complex_[c];
+        Slot* sl = &t.slots[s];
+        const uint32_t count = sl->count, slab = sl->slab;
+        const uint32_t* fmin = &w.cx_fmin[c * 1024];
+        uint32_t t_complete = 0, n_new = 0;
+        const uint32_t words = (count + 63) >> 6;
+        uint64_t bits0 = sl->bits;
+        for (uint32_t wd = lane; wd < words; wd += 64) {
+            uint64_t word = count > 64 ? slab_bitmap(t, slab)[wd] : bits0;
+            uint64_t add = 0;
+            for (uint32_t b = 0; b < 64 && wd * 64 + b < count; ++b) {
+                const uint32_t p = wd * 64 + b;
+                const uint32_t f = fmin[p];
+                if (f != IDX_NONE && !((word >> b) & 1)) {
+                    add |= 1ull << b;
+                    ++n_new;
+                    if (f > t_complete) t_complete = f;
+                }
+            }
+            if (add) {
+                if (count > 64) slab_bitmap(t, slab)[wd] = word | add;
+                else bits0 = word | add;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            n_new += __shfl_xor(n_new, off);
+            uint32_t o = __shfl_xor(t_complete, off);
+            if (o > t_complete) t_complete = o;
+        }
+        bits0 = __shfl(bits0, 0);
+        if (lane == 0) {
+            const uint32_t arrived_pre = count > 64 ? (uint32_t)sl->bits : (uint32_t)__popcll(sl->bits);
+            const uint32_t arrived = arrived_pre + n_new;
+            uint32_t T = IDX_NONE;
+            if (arrived_pre == count) T = 0;
+            else if (arrived == count) T = t_complete;
+            const uint64_t pa_pre = q_primary_at(t.q[s]);
+            const uint64_t at_min = w.cx_atmin[c];
+            w.cx_T[c] = T;
+            w.cx_nq[c] = pa_pre == NQ;
+            sl->bits = count > 64 ? (uint64_t)arrived : bits0;
+            sl->join_ts = now;
+            sl->chain = 0;
+            // events before T wait (store-nearest, redis.clj:269-271); from T on the barrier is queued at now
+            if (T != IDX_NONE) t.q[s] = now;
+            else if (pa_pre != NQ && at_min < pa_pre) t.q[s] = at_min;
+            a_max(&w.counters[C_MAXCHAIN], w.cx_cnt[c]);
+            if (w.cx_cnt[c] >= 256) sl->meta |= META_HOT; else sl->meta &= ~META_HOT;
+        }
+    }
+}
+
 // pass 3: messages of surviving events into the barrier's slab.  G lanes cooperate on one
 // message with 16-byte loads and stores; a wave handles 64/G events per step.
 template <int G>
 __global__ void __launch_bounds__(256) join_copy_kernel(Table t, Work w, const dj_join_rec* recs,
-                                                        const uint8_t* payloads, uint64_t pitch, uint32_t n) {
+                                                        const uint8_t* payloads, uint64_t pitch, uint32_t n,
+                                                        int32_t* status) {
     constexpr int EPW = 64 / G;                       // events per wave step
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t sub = lane / G, j0 = lane % G;
@@ -361,6 +515,7 @@ __global__ void __launch_bounds__(256) join_copy_kernel(Table t, Work w, const d
     const uint64_t waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     // the next batch's counters (the bank this batch does not use) start at zero
     if (blockIdx.x == 0 && threadIdx.x < C_COUNT) w.counters_next[threadIdx.x] = 0;
+    const bool hot = w.cx_on && w.counters[C_COMPLEX] != 0;
     for (uint64_t base = wave * EPW; base < n; base += waves * EPW) {
         const uint64_t i = base + sub;
         if (i >= n) continue;
@@ -368,6 +523,18 @@ __global__ void __launch_bounds__(256) join_copy_kernel(Table t, Work w, const d
         if (d == NODST) continue;
         const uint4 b = reinterpret_cast<const uint4*>(recs)[2 * i + 1];   // position, len, max_wait
         const uint32_t slab = (uint32_t)d, k = class_of((uint32_t)(d >> 32));
+        if (hot) {
+            // an event of a hot barrier gets its answer here, from the tables of the cx_* kernels
+            const uint32_t c = cx_lookup(w, slab);
+            if (c != IDX_NONE) {
+                const uint32_t T = w.cx_T[c];
+                if (j0 == 0) {
+                    if (T != IDX_NONE && i >= T) status[i] = DJ_JOIN_COMPLETE;
+                    else if (b.z && w.cx_nq[c]) status[i] = DJ_JOIN_NEAREST_NOT_QUEUED;
+                }
+                if (w.cx_fmax[c * 1024 + b.x] != (uint32_t)i + 1) continue;      // a later event of the batch wrote this position
+            }
+        }
         if (j0 == 0) slab_posmeta(t, slab, k)[b.x] = make_uint2(b.y, b.z);
         const uint4* src = reinterpret_cast<const uint4*>(payloads + i * pitch);
         uint4* dstp = reinterpret_cast<uint4*>(slab_payload(t, slab, k) + (uint64_t)b.x * t.stride);

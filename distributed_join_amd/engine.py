@@ -232,6 +232,10 @@ class Engine:
         self._check(self.L.dj_queue_scores(self.h, int(fp_lo), int(fp_hi), ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
+    def set_hot_path(self, mode):
+        """-1 automatic, 0 serial, 1 parallel kernels for barriers with long chains (same results)."""
+        self._check(self.L.dj_set_hot_path(self.h, int(mode)))
+
     def compact(self):
         """Rehash the live barriers into the spare table (drops tombstones); returns the live count."""
         live = ctypes.c_uint64(0)

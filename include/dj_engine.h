@@ -230,6 +230,12 @@ int dj_get_stats(dj_engine* e, dj_stats* h_stats);
  * synchronous.  *h_live (optional) = live slots. */
 int dj_compact(dj_engine* e, uint64_t* h_live);
 
+/* Barriers that receive very many events in one batch (hot keys, replays) are resolved by a
+ * parallel set of kernels instead of a serial walk; the engine switches by itself from the longest
+ * chain of the previous batch.  Both forms give identical results; this call pins the choice
+ * (-1 automatic, 0 serial, 1 parallel) so tests can exercise each.  No reference counterpart. */
+int dj_set_hot_path(dj_engine* e, int mode);
+
 /* ---- per-kernel timing (measurement aid; no counterpart in the reference) ---------- */
 /* Kernel ids for dj_profile_read.  With profiling enabled every launch of these kernels is
  * bracketed by a pair of HIP events on the engine's stream. */

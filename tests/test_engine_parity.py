@@ -16,11 +16,13 @@ pytestmark = pytest.mark.gpu
 T0 = 1_700_000_000_000
 
 
-def make_pair(oracle_lib, ids, stride, max_count=999, capacity=None, arena=256 << 20, max_batch=1 << 16, delay=2000):
+def make_pair(oracle_lib, ids, stride, max_count=999, capacity=None, arena=256 << 20, max_batch=1 << 16, delay=2000,
+              hot_mode=-1):
     from distributed_join_amd.engine import Engine
     e = Engine(capacity_barriers=capacity or max(len(ids), 64), arena_bytes=arena, max_count=max_count,
                payload_stride=stride, max_batch=max_batch, check_publish_delay_ms=delay, host_cap_conts=1 << 16,
                host_cap_positions=1 << 20)
+    e.set_hot_path(hot_mode)     # -1 automatic, 0 serial walk, 1 parallel kernels for long chains
     o = oracle_lib.Oracle(ids, max_count=max_count, payload_stride=stride, check_publish_delay_ms=delay)
     return e, o, ParityDriver(e, o, ids)
 
@@ -76,37 +78,40 @@ def run_oplog(d, rng, n_barriers, counts, stride, rounds, batch, hot=None, var_l
     d.check_all_snapshots()
 
 
-def test_small_counts_many_duplicates(oracle_lib):
+@pytest.mark.parametrize("hot_mode", [-1, 1])
+def test_small_counts_many_duplicates(oracle_lib, hot_mode):
     rng = np.random.default_rng(1)
     nb = 40
     ids = [f"j{b:x}~t{b:x}" for b in range(nb)] + [f"ghost{k}~x" for k in range(5)]
     counts = rng.integers(1, 9, nb)
-    e, o, d = make_pair(oracle_lib, ids, 64)
+    e, o, d = make_pair(oracle_lib, ids, 64, hot_mode=hot_mode)
     try:
         run_oplog(d, rng, nb, counts, 64, rounds=25, batch=400, unknown=5)
     finally:
         e.close()
 
 
-def test_hot_barrier_long_chains(oracle_lib):
+@pytest.mark.parametrize("hot_mode", [-1, 0, 1])
+def test_hot_barrier_long_chains(oracle_lib, hot_mode):
     rng = np.random.default_rng(2)
     nb = 30
     ids = [f"hot{b}~t{b}" for b in range(nb)]
     counts = rng.integers(2, 64, nb)
     counts[3] = 64
-    e, o, d = make_pair(oracle_lib, ids, 64)
+    e, o, d = make_pair(oracle_lib, ids, 64, hot_mode=hot_mode)
     try:
         run_oplog(d, rng, nb, counts, 64, rounds=20, batch=3000, hot=3)
     finally:
         e.close()
 
 
-def test_large_counts_multiword_bitmaps(oracle_lib):
+@pytest.mark.parametrize("hot_mode", [-1, 0, 1])
+def test_large_counts_multiword_bitmaps(oracle_lib, hot_mode):
     rng = np.random.default_rng(3)
     nb = 12
     ids = [f"big{b}~t{b}" for b in range(nb)]
     counts = np.array([65, 128, 129, 200, 999, 64, 63, 500, 70, 1, 2, 998])
-    e, o, d = make_pair(oracle_lib, ids, 64)
+    e, o, d = make_pair(oracle_lib, ids, 64, hot_mode=hot_mode)
     try:
         run_oplog(d, rng, nb, counts, 64, rounds=15, batch=4000, hot=4)
     finally:
