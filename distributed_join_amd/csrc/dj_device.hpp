@@ -154,6 +154,18 @@ __device__ inline bool a_cas(T* p, T expect, T v) {
 
 __device__ inline uint32_t lane_id() { return __lane_id(); }
 
+// Streamed bytes (messages on their way into or out of a slab) are touched once: non-temporal
+// loads and stores keep them from pushing the barrier table out of the caches.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ inline uint4 nt_load(const uint4* p) {
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ inline void nt_store(uint4* p, uint4 v) {
+    u32x4 x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<u32x4*>(p));
+}
+
 // Append one element per lane with pred set; one atomic per wave.  Must be reached by the
 // wave in converged control flow.  Returns the index, or 0xFFFFFFFF for lanes without pred.
 __device__ inline uint32_t wave_append(unsigned int* counter, bool pred) {

@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(256) join_copy_kernel(Table t, Work w, const d
         const uint4* src = reinterpret_cast<const uint4*>(payloads + i * pitch);
         uint4* dstp = reinterpret_cast<uint4*>(slab_payload(t, slab, k) + (uint64_t)b.x * t.stride);
         const uint32_t chunks = (b.y + 15) >> 4;
-        for (uint32_t c = j0; c < chunks; c += G) dstp[c] = src[c];
+        for (uint32_t c = j0; c < chunks; c += G) nt_store(&dstp[c], nt_load(&src[c]));
     }
 }
 
@@ -575,7 +575,7 @@ __device__ inline void fill_cont(dj_cont* c, const Slot& sl, uint64_t now, uint6
 // output indices for a chunk come from a block-wide prefix sum and ONE atomic on the packed
 // cursor word.  The cursors are raw (they may run past the caps); the gather pass (or
 // finish_result_kernel) publishes the clamped dj_sweep_result.
-constexpr int POP_ITEMS = 4;
+constexpr int POP_ITEMS = 16;
 
 __global__ void __launch_bounds__(256) pop_due_kernel(Table t, Work w, uint64_t now, uint32_t cap_conts,
                                                       uint64_t cap_pos, int alloc_pos, dj_cont* conts) {
@@ -695,8 +695,8 @@ __global__ void __launch_bounds__(256) gather_kernel(Table t, Work w, const dj_c
             const uint32_t p = it / CH, ch = it - p * CH;
             const bool present = count > 64 ? ((bm[p >> 6] >> (p & 63)) & 1) : ((bits0 >> p) & 1);
             if (!present || ch >= ((pm[p].x + 15) >> 4)) continue;
-            reinterpret_cast<uint4*>(payloads + (pos_base + p) * (uint64_t)t.stride)[ch] =
-                reinterpret_cast<const uint4*>(pay + (uint64_t)p * t.stride)[ch];
+            nt_store(&reinterpret_cast<uint4*>(payloads + (pos_base + p) * (uint64_t)t.stride)[ch],
+                     nt_load(&reinterpret_cast<const uint4*>(pay + (uint64_t)p * t.stride)[ch]));
         }
     }
     if (from_sweep && res && gtid == 0) publish_result(w, res, cap_conts, cap_pos);
