@@ -106,7 +106,7 @@ struct Table {
 struct Work {
     uint64_t* node;      // join link: next(25) | position(10) << 25 | max_wait(29) << 35
     uint64_t* dst;       // join: where the event's message goes, NODST = superseded / rejected
-    uint32_t* touched;   // slots touched by the current join batch (first toucher appends)
+    uint32_t* ev_slot;   // join: slot of event i (0xFFFFFFFF when the event was refused)
     uint32_t* complex_;  // slots whose chain is too long for the register path
     uint32_t* slot_of;   // fork: slot of record i
     uint32_t* cont_slot; // sweep: slot of continuation k
@@ -182,9 +182,40 @@ __device__ inline uint32_t wave_append(unsigned int* counter, bool pred) {
 // ---- probing -----------------------------------------------------------------------
 // Read-only lookup.  Valid in every kernel that does not insert (joins, sweeps, acks of
 // existing barriers): slot keys only change between launches there.
-__device__ inline int64_t find_slot(const Table& t, uint64_t lo, uint64_t hi) {
+// *info (optional) receives the slot's second 16 bytes {count, meta, slab, chain} as they were at the lookup.
+__device__ inline int64_t find_slot(const Table& t, uint64_t lo, uint64_t hi, uint4* info = nullptr) {
     uint64_t s = lo & t.mask;
-    for (uint64_t p = 0; p <= t.mask; ++p, s = (s + 1) & t.mask) {
+    if (info) {
+        const uint64_t s1 = (s + 1) & t.mask;
+        const ulonglong2 k0 = *reinterpret_cast<const ulonglong2*>(&t.slots[s]);
+        const uint4 i0 = reinterpret_cast<const uint4*>(&t.slots[s])[1];
+        const ulonglong2 k1 = *reinterpret_cast<const ulonglong2*>(&t.slots[s1]);
+        const uint4 i1 = reinterpret_cast<const uint4*>(&t.slots[s1])[1];
+        if (k0.x == lo && k0.y == hi) { *info = i0; return (int64_t)s; }
+        if (k0.x == FP_EMPTY) return -1;
+        if (k1.x == lo && k1.y == hi) { *info = i1; return (int64_t)s1; }
+        if (k1.x == FP_EMPTY) return -1;
+        s = (s1 + 1) & t.mask;
+        for (uint64_t p = 2; p <= t.mask; ++p, s = (s + 1) & t.mask) {
+            const ulonglong2 k = *reinterpret_cast<const ulonglong2*>(&t.slots[s]);
+            if (k.x == lo && k.y == hi) { *info = reinterpret_cast<const uint4*>(&t.slots[s])[1]; return (int64_t)s; }
+            if (k.x == FP_EMPTY) return -1;
+        }
+        return -1;
+    }
+    {
+        // The home slot and its neighbour are requested together: at load 0.5 a third of the keys
+        // sit one step from home, and a second dependent round trip costs more than 16 extra bytes.
+        const uint64_t s1 = (s + 1) & t.mask;
+        const ulonglong2 k0 = *reinterpret_cast<const ulonglong2*>(&t.slots[s]);
+        const ulonglong2 k1 = *reinterpret_cast<const ulonglong2*>(&t.slots[s1]);
+        if (k0.x == lo && k0.y == hi) return (int64_t)s;
+        if (k0.x == FP_EMPTY) return -1;
+        if (k1.x == lo && k1.y == hi) return (int64_t)s1;
+        if (k1.x == FP_EMPTY) return -1;
+        s = (s1 + 1) & t.mask;
+    }
+    for (uint64_t p = 2; p <= t.mask; ++p, s = (s + 1) & t.mask) {
         const ulonglong2 k = *reinterpret_cast<const ulonglong2*>(&t.slots[s]);
         if (k.x == lo && k.y == hi) return (int64_t)s;
         if (k.x == FP_EMPTY) return -1;

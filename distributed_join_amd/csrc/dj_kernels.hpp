@@ -127,7 +127,6 @@ constexpr int LINK_BLOCK = 1024;
 
 __global__ void __launch_bounds__(LINK_BLOCK) join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n,
                                                                uint64_t pitch, int32_t* status) {
-    __shared__ uint32_t lds[17];
     // Block-level pre-aggregation for barriers flagged hot: their events are chained inside the block
     // through LDS and the block issues ONE exchange per hot barrier (a contended returning atomic
     // costs ~60 ns, ten thousand of them on one word would serialise the whole pass).
@@ -139,7 +138,6 @@ __global__ void __launch_bounds__(LINK_BLOCK) join_link_kernel(Table t, Work w, 
     if (threadIdx.x < HOT_KEYS) { hot_key[threadIdx.x] = 0; hot_cnt[threadIdx.x] = 0; }
     __syncthreads();
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool first = false;
     uint32_t slot = 0;
     int agg_key = -1;
     uint32_t agg_rank = 0, agg_pos = 0, agg_mw = 0;
@@ -148,23 +146,26 @@ __global__ void __launch_bounds__(LINK_BLOCK) join_link_kernel(Table t, Work w, 
         const uint4 b = reinterpret_cast<const uint4*>(recs)[2 * (size_t)i + 1];  // position, len, max_wait, -
         int32_t st = 0;
         int64_t s = -1;
+        uint4 info = make_uint4(0, 0, 0, 0);               // count, meta, slab, chain of the slot
         if (b.y > t.stride || b.y > pitch) {
             st = DJ_JOIN_TOO_LONG;                         // store.clj:24-26
         } else {
-            s = find_slot(t, a.x, a.y);
-            if (s < 0 || !(t.slots[s].meta & META_HAS) || t.slots[s].slab == 0) st = DJ_JOIN_NOT_FOUND;   // redis.clj:152
-            else if (b.x >= t.slots[s].count) st = DJ_JOIN_BAD_POSITION;          // redis.clj:153
+            s = find_slot(t, a.x, a.y, &info);
+            if (s < 0 || !(info.y & META_HAS) || info.z == 0) st = DJ_JOIN_NOT_FOUND;   // redis.clj:152
+            else if (b.x >= info.x) st = DJ_JOIN_BAD_POSITION;                          // redis.clj:153
         }
         if (st != 0) {
             status[i] = st;
             w.dst[i] = NODST;
+            w.ev_slot[i] = 0xFFFFFFFFu;
         } else {
             // the common answers are written here, coalesced; the resolve pass only overwrites the
             // exceptions (COMPLETE / NEAREST_NOT_QUEUED statuses, superseded messages)
             status[i] = DJ_JOIN_WAITING;
-            w.dst[i] = dst_pack(t.slots[s].slab, t.slots[s].count);
+            w.dst[i] = dst_pack(info.z, info.x);
             slot = (uint32_t)s;
-            if (t.slots[s].meta & META_HOT) {
+            w.ev_slot[i] = slot;
+            if (info.y & META_HOT) {
                 for (int j = 0; j < HOT_KEYS && agg_key < 0; ++j) {
                     const uint32_t k = atomicCAS(&hot_key[j], 0u, slot + 1);
                     if (k == 0 || k == slot + 1) {
@@ -180,7 +181,6 @@ __global__ void __launch_bounds__(LINK_BLOCK) join_link_kernel(Table t, Work w, 
             if (agg_key < 0) {
                 const uint32_t prev = a_xchg(&t.slots[s].chain, i + 1);
                 w.node[i] = node_pack(prev, b.x, b.z);
-                first = prev == 0;
             }
         }
     }
@@ -194,10 +194,7 @@ __global__ void __launch_bounds__(LINK_BLOCK) join_link_kernel(Table t, Work w, 
         // element r links to element r-1 of its block-local list, element 0 to the chain as it was
         const uint32_t next = agg_rank == 0 ? hot_prev[agg_key] : hot_list[agg_key][agg_rank - 1];
         w.node[i] = node_pack(next, agg_pos, agg_mw);
-        first = agg_rank == 0 && next == 0;
     }
-    uint32_t at = block_append(&w.counters[C_TOUCHED], first, lds);
-    if (first) w.touched[at] = slot;
 }
 
 // Sequential replay of one barrier's events e[0..m) (sorted by array index) — the body of
@@ -235,15 +232,22 @@ __device__ inline int32_t replay_one(const Table& t, uint64_t s, uint32_t slab, 
 
 constexpr int CHAIN_REG = 8;   // chains up to this length are replayed from registers
 
-__global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint64_t now, int32_t* status) {
-    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint32_t n, uint64_t now, int32_t* status) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     bool is_complex = false;
-    uint32_t s = 0;
-    if (tid < w.counters[C_TOUCHED]) {
-        s = w.touched[tid];
+    uint32_t s = tid < n ? w.ev_slot[tid] : 0xFFFFFFFFu;
+    uint4 info = make_uint4(0, 0, 0, 0);
+    uint64_t bits0 = 0;
+    if (s != 0xFFFFFFFFu) {
+        info = reinterpret_cast<const uint4*>(&t.slots[s])[1];   // count, meta, slab, chain
+        bits0 = t.slots[s].bits;                                 // requested with it: one round trip
+    }
+    // The event at the head of a barrier's chain (the last one linked) resolves the barrier; every
+    // other event of the chain sees another index (or 0 once the head is done) and leaves.
+    if (s != 0xFFFFFFFFu && info.w == tid + 1) {
         Slot* sl = &t.slots[s];
-        const uint32_t count = sl->count, slab = sl->slab;
-        uint32_t cur = sl->chain;
+        const uint32_t count = info.x, slab = info.z;
+        uint32_t cur = info.w;
         // walk the chain (newest link first)
         uint32_t idx[CHAIN_REG];
         uint64_t nd[CHAIN_REG];
@@ -273,8 +277,8 @@ __global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint
                     }
             ReplayState r;
             r.count = count;
-            r.bits = count > 64 ? 0 : sl->bits;
-            r.arrived = count > 64 ? (uint32_t)sl->bits : (uint32_t)__popcll(sl->bits);
+            r.bits = count > 64 ? 0 : bits0;
+            r.arrived = count > 64 ? (uint32_t)bits0 : (uint32_t)__popcll(bits0);
             r.pa = NQ; r.pa_loaded = false; r.pa_dirty = false; r.enq = false;
 #pragma unroll
             for (int k = 0; k < CHAIN_REG; ++k) {
@@ -292,7 +296,7 @@ __global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint
             sl->bits = count > 64 ? (uint64_t)r.arrived : r.bits;
             sl->join_ts = now;                              // SET <id>:join-ts, redis.clj:136
             sl->chain = 0;
-            if (sl->meta & META_HOT) sl->meta &= ~META_HOT; // a short chain: not hot any more
+            if (info.y & META_HOT) sl->meta = info.y & ~META_HOT; // a short chain: not hot any more
             if (r.enq) t.q[s] = now;                    // ZADD both at now, redis.clj:257-258
             else if (r.pa_dirty) t.q[s] = r.pa;         // ZADD both at the nearer date, redis.clj:270-271
         }

@@ -1,0 +1,96 @@
+// Memory-system ceilings of one GPU for the access shapes the barrier engine uses:
+//   copy      : streaming 16-byte loads/stores over 1 GiB (the classic HBM number)
+//   rand_rd   : one random 64-byte table line per thread, 8 bytes read from it
+//   rand_rmw  : the same, plus an 8-byte store into the line (what join_link does to a slot)
+//   rand_xchg : the same with an atomic exchange instead of load+store
+//   rand_wr64 : one full random 64-byte line written per 4 lanes (what join_copy does at P=64)
+// Build: hipcc --offload-arch=gfx950 -O3 -o membench tools/membench.hip ; run: ./membench
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__device__ inline uint64_t mix(uint64_t x) {
+    x += 0x9e3779b97f4a7c15ull; x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull; return x ^ (x >> 31);
+}
+
+__global__ void copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) dst[i] = src[i];
+}
+
+__global__ void rand_rd_kernel(const uint64_t* __restrict__ tab, uint64_t line_mask, uint32_t n, uint64_t seed,
+                               uint64_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t line = mix(seed + i) & line_mask;
+    uint64_t v = tab[line * 8];
+    if (v == 0x1234567) out[0] = v;          // never true; keeps the load
+}
+
+__global__ void rand_rmw_kernel(uint64_t* __restrict__ tab, uint64_t line_mask, uint32_t n, uint64_t seed) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t line = mix(seed + i) & line_mask;
+    uint64_t v = tab[line * 8];
+    tab[line * 8 + 3] = v + i;
+}
+
+__global__ void rand_xchg_kernel(uint64_t* __restrict__ tab, uint64_t line_mask, uint32_t n, uint64_t seed,
+                                 uint64_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t line = mix(seed + i) & line_mask;
+    uint64_t v = tab[line * 8];
+    uint32_t old = atomicExch(reinterpret_cast<uint32_t*>(&tab[line * 8 + 3]), i + (uint32_t)v);
+    if (old == 0xfffffff3u) out[0] = old;
+}
+
+__global__ void rand_wr64_kernel(uint4* __restrict__ tab, uint64_t line_mask, uint32_t n, uint64_t seed) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = t >> 2, c = t & 3;
+    if (i >= n) return;
+    uint64_t line = mix(seed + i) & line_mask;
+    tab[line * 4 + c] = make_uint4(i, c, i, c);
+}
+
+template <class F> static float time_ms(F f, int reps) {
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    f(0); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int r = 0; r < reps; ++r) f(r + 1);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b));
+    return ms / reps;
+}
+
+int main() {
+    const size_t GiB = 1ull << 30;
+    uint4 *src, *dst; uint64_t* out;
+    CK(hipMalloc(&src, GiB)); CK(hipMalloc(&dst, GiB)); CK(hipMalloc(&out, 64));
+    CK(hipMemset(src, 1, GiB)); CK(hipMemset(dst, 0, GiB));
+    const size_t n16 = GiB / 16;
+    float ms = time_ms([&](int) { copy_kernel<<<256 * 16, 256>>>(src, dst, n16); }, 10);
+    printf("copy 1 GiB            : %.3f ms  %.0f GB/s (read+write)\n", ms, 2.0 * GiB / ms / 1e6);
+
+    const uint32_t n = 1u << 20;
+    for (size_t tab_bytes : {size_t(128) << 20, size_t(1) << 30}) {
+        uint64_t line_mask = tab_bytes / 64 - 1;
+        uint64_t* tab = reinterpret_cast<uint64_t*>(dst);
+        printf("table %4zu MiB, %u random 64-byte lines per launch\n", tab_bytes >> 20, n);
+        ms = time_ms([&](int r) { rand_rd_kernel<<<n / 256, 256>>>(tab, line_mask, n, 7777ull * r, out); }, 20);
+        printf("  rand_rd   : %7.1f us  %.1f G lines/s\n", ms * 1e3, n / ms / 1e6);
+        ms = time_ms([&](int r) { rand_rmw_kernel<<<n / 256, 256>>>(tab, line_mask, n, 7777ull * r); }, 20);
+        printf("  rand_rmw  : %7.1f us  %.1f G lines/s\n", ms * 1e3, n / ms / 1e6);
+        ms = time_ms([&](int r) { rand_xchg_kernel<<<n / 256, 256>>>(tab, line_mask, n, 7777ull * r, out); }, 20);
+        printf("  rand_xchg : %7.1f us  %.1f G lines/s\n", ms * 1e3, n / ms / 1e6);
+        ms = time_ms([&](int r) { rand_wr64_kernel<<<n * 4 / 256, 256>>>(reinterpret_cast<uint4*>(tab), line_mask, n, 7777ull * r); }, 20);
+        printf("  rand_wr64 : %7.1f us  %.1f G lines/s\n", ms * 1e3, n / ms / 1e6);
+    }
+    CK(hipFree(src)); CK(hipFree(dst)); CK(hipFree(out));
+    return 0;
+}
