@@ -72,10 +72,62 @@ def cpu_baseline(count, payload):
         o.ack_batch(conts, None, now)
     dt = time.perf_counter() - t
     assert fired == nb
-    return {"value": nb * count / dt, "unit": "join events/s", "cores": 1, "kind": "port",
+    out = {"value": nb * count / dt, "unit": "join events/s", "cores": 1, "kind": "port",
+           "continuations_per_s": nb / dt,
+           "sample": f"{nb} barriers x count {count}, {payload} B messages, {count} batches of {nb} joins, "
+                     "sweep + ack per batch, single thread, in-process (no Redis round trips)"}
+    del o
+    out["sharded"] = cpu_baseline_sharded(count, payload)
+    return out
+
+
+def cpu_baseline_sharded(count, payload):
+    """The same op-log on every host core this process may use: barriers are hash-sharded over T
+    independent oracle instances (barrier b -> shard b % T), one thread each (the oracle's C calls
+    run without the interpreter lock).  The op-log is partitioned before the clock starts."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle_py
+    T = max(1, min(16, len(os.sched_getaffinity(0))))
+    nb = (1 << 18) // T * T
+    per = nb // T
+    ids = make_ids(0, nb)
+    shards = [oracle_py.Oracle(ids[t::T], max_count=count, payload_stride=payload) for t in range(T)]
+    rng = np.random.default_rng(3)
+    ev = rng.permutation(nb * count)
+    pay = rng.integers(0, 256, (2 * per, payload), dtype=np.uint8)
+    plan = []      # plan[t][k] = (barrier index inside the shard, position) of batch k
+    for t in range(T):
+        mine = []
+        for k in range(count):
+            part = ev[k * nb:(k + 1) * nb]
+            b = part // count
+            sel = part[b % T == t]
+            mine.append(((sel // count) // T, sel % count))
+        plan.append(mine)
+    now0 = 1_700_000_000_000
+
+    def run(t):
+        o, now, fired = shards[t], now0, 0
+        o.fork_batch(np.arange(per), np.full(per, count), np.full(per, now + 3_600_000))
+        for k in range(count):
+            now += 1
+            b, p = plan[t][k]
+            m = len(b)
+            o.join_batch(b, p, np.full(m, payload), np.zeros(m), pay[:m], now)
+            conts, _, _, _ = o.sweep(now, cap_conts=per, cap_positions=per * count)
+            fired += len(conts)
+            o.ack_batch(conts, None, now)
+        return fired
+
+    with ThreadPoolExecutor(T) as ex:
+        t0 = time.perf_counter()
+        fired = sum(ex.map(run, range(T)))
+        dt = time.perf_counter() - t0
+    assert fired == nb
+    return {"value": nb * count / dt, "unit": "join events/s", "cores": T, "kind": "port",
             "continuations_per_s": nb / dt,
-            "sample": f"{nb} barriers x count {count}, {payload} B messages, {count} batches of {nb} joins, "
-                      "sweep + ack per batch, single thread, in-process (no Redis round trips)"}
+            "sample": f"{nb} barriers x count {count} hash-sharded over {T} oracle instances / threads, "
+                      f"{count} batches, sweep + ack per batch"}
 
 
 def main():
@@ -260,6 +312,17 @@ def main():
                     "unit": "GB/s", "frac": round(kernels[dom]["achieved_GBps"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "avg_launch_ms": kernels[dom]["avg_ms"],
                     "alg_bytes_per_launch": kernels[dom]["alg_bytes_per_launch"]}
+        # measured streaming ceiling of this GPU beside the spec peak: device-to-device copy of 1 GiB
+        src, dst = torch.empty(1 << 30, dtype=torch.uint8, device=dev), torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        dst.copy_(src)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(5):
+            dst.copy_(src)
+        c1.record()
+        torch.cuda.synchronize()
+        roofline["measured_copy_GBps"] = round(5 * 2 * (1 << 30) / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)
+        del src, dst
         # the whole join path (link + resolve + copy) against SURVEY's per-event figure 112 + 2P
         jt = sum(kernels[k]["avg_ms"] for k in ("join_link", "join_resolve", "join_complex", "join_copy") if k in kernels)
         roofline["join_path"] = {"alg_bytes_per_event": 112 + 2 * P, "ms_per_batch": round(jt, 4),
