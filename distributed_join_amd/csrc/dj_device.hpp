@@ -400,6 +400,38 @@ __device__ inline void wave_slab_free(const Table& t, bool has, uint32_t k, uint
     }
 }
 
+// Block-cooperative form: ONE ring push per block for the block's dominant class (acks of a sweep
+// free thousands of slabs of one class; a push per wave would queue up on the ring's tail word),
+// other classes go through the wave path.  Every thread of the block must call it.
+// lds: 24 words of shared memory.
+__device__ inline void block_slab_free(const Table& t, bool has, uint32_t k, uint32_t slab, uint32_t* lds) {
+    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    has = has && slab != 0;
+    if (threadIdx.x == 0) lds[16] = 0xFFFFFFFFu;
+    __syncthreads();
+    const uint64_t hm = __ballot(has);
+    if (hm && (int)lane == __ffsll((unsigned long long)hm) - 1) atomicMin(&lds[16], k);   // one candidate per wave
+    __syncthreads();
+    const uint32_t kb = lds[16];
+    if (kb == 0xFFFFFFFFu) return;                         // nothing to free (uniform across the block)
+    const bool fast = has && k == kb;
+    const uint64_t m = __ballot(fast);
+    if (lane == 0) lds[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (uint32_t v = 0; v < nw; ++v) { const uint32_t c = lds[v]; lds[v] = tot; tot += c; }
+        lds[17] = tot ? a_add(&t.ring_tail[kb], tot) : 0u;
+    }
+    __syncthreads();
+    if (fast) {
+        const uint32_t rank = lds[wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        t.ring[kb][(lds[17] + rank) & (t.ring_cap[kb] - 1)] = slab;
+    }
+    __syncthreads();
+    wave_slab_free(t, has && !fast, k, slab);
+}
+
 // redis/complete's deletions (redis.clj:180-185) for a slot this thread owns.  The slab goes
 // back through wave_slab_free by the caller.
 __device__ inline void clear_slot(const Table& t, uint64_t s) {

@@ -500,7 +500,7 @@ extern "C" int dj_ack_batch(dj_engine* e, uint32_t n, const uint32_t* d_n, const
     if (n == 0) return DJ_OK;
     if (!d_conts || !d_status) return fail(e, DJ_E_INVALID, "ack: null pointer");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
-    LAUNCH(e, DJ_PROF_ACK, (ack_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, n, d_n, d_conts, d_ok, now_ms, d_status)));
+    LAUNCH(e, DJ_PROF_ACK, (ack_kernel<<<grid_for(n, ACK_BLOCK), ACK_BLOCK, 0, e->stream>>>(e->t, n, d_n, d_conts, d_ok, now_ms, d_status)));
     HIP_TRY(e, hipGetLastError());
     return DJ_OK;
 }

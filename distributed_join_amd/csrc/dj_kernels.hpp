@@ -575,67 +575,85 @@ __device__ inline void fill_cont(dj_cont* c, const Slot& sl, uint64_t now, uint6
 }
 
 // One pass over q[]: every slot with q <= now (in the primary queue, score <= now) is popped
-// (ZRANGEBYSCORE + ZREMRANGEBYSCORE 0 now).  A block scans chunks of 256 * POP_ITEMS slots;
-// output indices for a chunk come from a block-wide prefix sum and ONE atomic on the packed
-// cursor word.  The cursors are raw (they may run past the caps); the gather pass (or
+// (ZRANGEBYSCORE + ZREMRANGEBYSCORE 0 now).  A block scans chunks of 256 * POP_ITEMS queue words
+// with POP_ITEMS loads in flight per thread and collects the due slots in a list in LDS; the list
+// is then worked off one entry per thread (one slot read each, descriptors written to consecutive
+// indices).  Output indices come from a block-wide prefix sum and ONE atomic on the packed cursor
+// word per 256 entries.  The cursors are raw (they may run past the caps); the gather pass (or
 // finish_result_kernel) publishes the clamped dj_sweep_result.
 constexpr int POP_ITEMS = 16;
 
 __global__ void __launch_bounds__(256) pop_due_kernel(Table t, Work w, uint64_t now, uint32_t cap_conts,
                                                       uint64_t cap_pos, int alloc_pos, dj_cont* conts) {
+    __shared__ uint16_t list[256 * POP_ITEMS];     // offsets of the chunk's due slots
+    __shared__ uint32_t list_n;
     __shared__ uint32_t wave_c[4], wave_p[4];
     __shared__ unsigned long long base_s;
     const uint64_t nslots = t.mask + 1;
     const uint64_t chunk = 256ull * POP_ITEMS;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (uint64_t cb = blockIdx.x * chunk; cb < nslots; cb += (uint64_t)gridDim.x * chunk) {
-        uint32_t nd = 0, ps = 0, due_mask = 0;
-        uint32_t cnts[POP_ITEMS];
+        if (tid == 0) list_n = 0;
+        __syncthreads();
+        uint32_t due_mask = 0;
 #pragma unroll
         for (int j = 0; j < POP_ITEMS; ++j) {
             const uint64_t s = cb + (uint64_t)j * 256 + tid;
-            cnts[j] = 0;
-            if (s < nslots && t.q[s] <= now) {
-                const uint2 cm = *reinterpret_cast<const uint2*>(&t.slots[s].count);   // count, meta
-                cnts[j] = (alloc_pos && (cm.y & META_HAS)) ? cm.x : 0;
-                due_mask |= 1u << j;
-                ++nd;
-                ps += cnts[j];
+            if (s < nslots && t.q[s] <= now) due_mask |= 1u << j;
+        }
+        const uint32_t nd = (uint32_t)__popc(due_mask);
+        const uint32_t incl = wave_incl_scan(nd);
+        const uint32_t wtot = __shfl(incl, 63);
+        if (wtot) {                                 // uniform across the wave
+            uint32_t wbase = 0;
+            if (lane == 63) wbase = atomicAdd(&list_n, wtot);
+            wbase = __shfl(wbase, 63);
+            uint32_t at = wbase + incl - nd;
+            for (uint32_t mk = due_mask; mk; mk &= mk - 1)
+                list[at++] = (uint16_t)((__ffs(mk) - 1) * 256 + tid);
+        }
+        __syncthreads();
+        const uint32_t ln = list_n;
+        for (uint32_t r = 0; r < ln; r += 256) {    // uniform across the block
+            const uint32_t e = r + tid;
+            const bool has = e < ln;
+            uint64_t s = 0, pa = 0;
+            uint32_t cnt = 0;
+            Slot sl;
+            if (has) {
+                s = cb + list[e];
+                sl = t.slots[s];
+                pa = t.q[s];
+                cnt = (alloc_pos && (sl.meta & META_HAS)) ? sl.count : 0;
             }
-        }
-        const uint32_t incl_c = wave_incl_scan(nd), incl_p = wave_incl_scan(ps);
-        if (lane == 63) { wave_c[wv] = incl_c; wave_p[wv] = incl_p; }
-        __syncthreads();
-        if (tid == 0) {
-            const unsigned long long tc = wave_c[0] + wave_c[1] + wave_c[2] + wave_c[3];
-            const unsigned long long tp = wave_p[0] + wave_p[1] + wave_p[2] + wave_p[3];
-            base_s = tc ? a_add(&w.sweep[S_CURSOR], tc | (tp << CURSOR_SHIFT)) : 0ull;
-        }
-        __syncthreads();
-        uint32_t my_c = (uint32_t)(base_s & CURSOR_CONT_MASK) + incl_c - nd;
-        uint64_t my_p = (base_s >> CURSOR_SHIFT) + incl_p - ps;
-        for (uint32_t v = 0; v < wv; ++v) { my_c += wave_c[v]; my_p += wave_p[v]; }
-#pragma unroll
-        for (int j = 0; j < POP_ITEMS; ++j) {
-            if (!(due_mask & (1u << j))) continue;
-            const uint64_t s = cb + (uint64_t)j * 256 + tid;
-            const uint32_t c_idx = my_c++;
-            const uint64_t p_idx = my_p;
-            my_p += cnts[j];
-            if (c_idx >= cap_conts) { w.sweep[S_MORE] = 1; continue; }
-            if (alloc_pos && p_idx + cnts[j] > cap_pos) {
-                w.sweep[S_MORE] = 1;
-                conts[c_idx].flags = CONT_VOID;      // index taken, barrier stays queued
-                conts[c_idx].count = 0;
-                w.cont_slot[c_idx] = 0xFFFFFFFFu;
-                continue;
+            const uint32_t incl_c = wave_incl_scan(has ? 1u : 0u), incl_p = wave_incl_scan(cnt);
+            if (lane == 63) { wave_c[wv] = incl_c; wave_p[wv] = incl_p; }
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned long long tc = wave_c[0] + wave_c[1] + wave_c[2] + wave_c[3];
+                const unsigned long long tp = wave_p[0] + wave_p[1] + wave_p[2] + wave_p[3];
+                base_s = a_add(&w.sweep[S_CURSOR], tc | (tp << CURSOR_SHIFT));
             }
-            const uint64_t pa = t.q[s];
-            t.q[s] = pa | Q_POPPED;                 // popped; the backup entry stays (redis.clj:288)
-            fill_cont(&conts[c_idx], t.slots[s], now, pa, p_idx, s + 1);
-            w.cont_slot[c_idx] = (uint32_t)s;
+            __syncthreads();
+            uint32_t c_idx = (uint32_t)(base_s & CURSOR_CONT_MASK) + incl_c - 1;
+            uint64_t p_idx = (base_s >> CURSOR_SHIFT) + incl_p - cnt;
+            for (uint32_t v = 0; v < wv; ++v) { c_idx += wave_c[v]; p_idx += wave_p[v]; }
+            if (has) {
+                if (c_idx >= cap_conts) {
+                    w.sweep[S_MORE] = 1;
+                } else if (alloc_pos && p_idx + cnt > cap_pos) {
+                    w.sweep[S_MORE] = 1;
+                    conts[c_idx].flags = CONT_VOID;      // index taken, barrier stays queued
+                    conts[c_idx].count = 0;
+                    w.cont_slot[c_idx] = 0xFFFFFFFFu;
+                } else {
+                    t.q[s] = pa | Q_POPPED;              // popped; the backup entry stays (redis.clj:288)
+                    fill_cont(&conts[c_idx], sl, now, pa, p_idx, s + 1);
+                    w.cont_slot[c_idx] = (uint32_t)s;
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
@@ -740,10 +758,14 @@ __device__ inline void retry_requeue(const Table& t, uint64_t s, bool timeout, u
     t.q[s] = now;
 }
 
-__global__ void __launch_bounds__(256) ack_kernel(Table t, uint32_t n_max, const uint32_t* d_n, const dj_cont* conts,
-                                                  const uint8_t* ok, uint64_t now, int32_t* status) {
+constexpr int ACK_BLOCK = 1024;
+
+__global__ void __launch_bounds__(ACK_BLOCK) ack_kernel(Table t, uint32_t n_max, const uint32_t* d_n, const dj_cont* conts,
+                                                        const uint8_t* ok, uint64_t now, int32_t* status) {
+    __shared__ uint32_t lds[24];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = d_n ? (*d_n < n_max ? *d_n : n_max) : n_max;
+    if (blockIdx.x * blockDim.x >= n) return;          // the whole block is beyond the end
     // ---- phase A (per lane): decide -----------------------------------------------------------
     int32_t st = 0;
     bool clear = false, free_old = false, alloc = false, write_back = false, timeout = false;
@@ -812,8 +834,8 @@ __global__ void __launch_bounds__(256) ack_kernel(Table t, uint32_t n_max, const
             }
         }
     }
-    // ---- phase B (wave-cooperative): slab traffic, one atomic per size class -------------------
-    wave_slab_free(t, free_old, k_old, old_slab);
+    // ---- phase B (block- and wave-cooperative): slab traffic, one atomic per size class ---------
+    block_slab_free(t, free_old, k_old, old_slab, lds);
     const uint32_t fresh = wave_slab_alloc(t, alloc, k_new);
     // ---- phase C (per lane): finish ------------------------------------------------------------------
     if (clear) clear_slot(t, s_u);
