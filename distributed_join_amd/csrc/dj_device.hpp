@@ -180,45 +180,35 @@ __device__ inline uint32_t wave_append(unsigned int* counter, bool pred) {
 }
 
 // ---- probing -----------------------------------------------------------------------
+// The memory system moves aligned 128-byte blocks (two slots): a second slot of the same block
+// costs nothing, a slot of another block costs a full random access.  The probe sequence
+// therefore visits the home slot h, its block partner h ^ 1, then the following blocks in order:
+//   p = 0: h,  p = 1: h ^ 1,  p >= 2: ((h & ~1) + p) & mask          (every slot exactly once)
+__device__ inline uint64_t probe_at(uint64_t h, uint64_t p, uint64_t mask) {
+    return p == 0 ? h : (p == 1 ? (h ^ 1) : (((h & ~1ull) + p) & mask));
+}
+
 // Read-only lookup.  Valid in every kernel that does not insert (joins, sweeps, acks of
-// existing barriers): slot keys only change between launches there.
+// existing barriers): slot keys only change between launches there.  Both slots of a block are
+// requested together.
 // *info (optional) receives the slot's second 16 bytes {count, meta, slab, chain} as they were at the lookup.
 __device__ inline int64_t find_slot(const Table& t, uint64_t lo, uint64_t hi, uint4* info = nullptr) {
-    uint64_t s = lo & t.mask;
-    if (info) {
-        const uint64_t s1 = (s + 1) & t.mask;
-        const ulonglong2 k0 = *reinterpret_cast<const ulonglong2*>(&t.slots[s]);
-        const uint4 i0 = reinterpret_cast<const uint4*>(&t.slots[s])[1];
+    const uint64_t h = lo & t.mask;
+    uint64_t s0 = h, s1 = h ^ 1;
+    for (uint64_t p = 0; p <= t.mask; p += 2) {
+        const ulonglong2 k0 = *reinterpret_cast<const ulonglong2*>(&t.slots[s0]);
         const ulonglong2 k1 = *reinterpret_cast<const ulonglong2*>(&t.slots[s1]);
-        const uint4 i1 = reinterpret_cast<const uint4*>(&t.slots[s1])[1];
-        if (k0.x == lo && k0.y == hi) { *info = i0; return (int64_t)s; }
-        if (k0.x == FP_EMPTY) return -1;
-        if (k1.x == lo && k1.y == hi) { *info = i1; return (int64_t)s1; }
-        if (k1.x == FP_EMPTY) return -1;
-        s = (s1 + 1) & t.mask;
-        for (uint64_t p = 2; p <= t.mask; ++p, s = (s + 1) & t.mask) {
-            const ulonglong2 k = *reinterpret_cast<const ulonglong2*>(&t.slots[s]);
-            if (k.x == lo && k.y == hi) { *info = reinterpret_cast<const uint4*>(&t.slots[s])[1]; return (int64_t)s; }
-            if (k.x == FP_EMPTY) return -1;
+        uint4 i0 = make_uint4(0, 0, 0, 0), i1 = i0;
+        if (info) {
+            i0 = reinterpret_cast<const uint4*>(&t.slots[s0])[1];
+            i1 = reinterpret_cast<const uint4*>(&t.slots[s1])[1];
         }
-        return -1;
-    }
-    {
-        // The home slot and its neighbour are requested together: at load 0.5 a third of the keys
-        // sit one step from home, and a second dependent round trip costs more than 16 extra bytes.
-        const uint64_t s1 = (s + 1) & t.mask;
-        const ulonglong2 k0 = *reinterpret_cast<const ulonglong2*>(&t.slots[s]);
-        const ulonglong2 k1 = *reinterpret_cast<const ulonglong2*>(&t.slots[s1]);
-        if (k0.x == lo && k0.y == hi) return (int64_t)s;
+        if (k0.x == lo && k0.y == hi) { if (info) *info = i0; return (int64_t)s0; }
         if (k0.x == FP_EMPTY) return -1;
-        if (k1.x == lo && k1.y == hi) return (int64_t)s1;
+        if (k1.x == lo && k1.y == hi) { if (info) *info = i1; return (int64_t)s1; }
         if (k1.x == FP_EMPTY) return -1;
-        s = (s1 + 1) & t.mask;
-    }
-    for (uint64_t p = 2; p <= t.mask; ++p, s = (s + 1) & t.mask) {
-        const ulonglong2 k = *reinterpret_cast<const ulonglong2*>(&t.slots[s]);
-        if (k.x == lo && k.y == hi) return (int64_t)s;
-        if (k.x == FP_EMPTY) return -1;
+        s0 = ((h & ~1ull) + p + 2) & t.mask;
+        s1 = s0 + 1;
     }
     return -1;
 }
@@ -230,10 +220,11 @@ __device__ inline int64_t find_slot(const Table& t, uint64_t lo, uint64_t hi, ui
 __device__ inline int64_t find_or_claim(const Table& t, uint64_t lo, uint64_t hi, bool* created) {
     *created = false;
     for (int attempt = 0; attempt < 64; ++attempt) {
-        uint64_t s = lo & t.mask;
+        const uint64_t h = lo & t.mask;
         int64_t tomb = -1;
         bool restart = false;
-        for (uint64_t p = 0; p <= t.mask && !restart; ++p, s = (s + 1) & t.mask) {
+        for (uint64_t p = 0; p <= t.mask && !restart; ++p) {
+            const uint64_t s = probe_at(h, p, t.mask);
             Slot* sl = &t.slots[s];
             uint64_t klo = sl->fp_lo;
             if (klo == FP_EMPTY || klo == FP_TOMB) klo = a_load(&sl->fp_lo);

@@ -394,7 +394,10 @@ extern "C" int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs
     e->w.counters_next = e->d_counters + (e->ctr_bank ^ 1) * C_COUNT;
     e->ctr_bank ^= 1;
     e->w.cx_on = e->cx_force >= 0 ? (uint32_t)e->cx_force : (*(volatile unsigned int*)e->h_maxchain >= 256 ? 1u : 0u);
-    LAUNCH(e, DJ_PROF_JOIN_LINK, (join_link_kernel<<<grid_for(n, LINK_BLOCK), LINK_BLOCK, 0, e->stream>>>(e->t, e->w, d_recs, n, pitch, d_status)));
+    if (e->w.cx_on)
+        LAUNCH(e, DJ_PROF_JOIN_LINK, (join_link_kernel<true><<<grid_for(n, LINK_BLOCK_HOT), LINK_BLOCK_HOT, 0, e->stream>>>(e->t, e->w, d_recs, n, pitch, d_status)));
+    else
+        LAUNCH(e, DJ_PROF_JOIN_LINK, (join_link_kernel<false><<<grid_for(n, LINK_BLOCK), LINK_BLOCK, 0, e->stream>>>(e->t, e->w, d_recs, n, pitch, d_status)));
     LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, (uint32_t)n, now_ms, d_status)));
     // Long chains (hot barriers): the previous batch's longest chain, read back without waiting, picks
     // between the serial kernel and the parallel cx_* kernels.  Both give the same results.

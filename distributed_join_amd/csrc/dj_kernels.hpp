@@ -123,20 +123,26 @@ __device__ inline uint32_t block_append(unsigned int* counter, bool pred, uint32
     return pred ? r : 0xFFFFFFFFu;
 }
 
-constexpr int LINK_BLOCK = 1024;
+// HOT = false: independent threads, blocks of 256 (no barrier anywhere: a thread with a long probe
+// sequence delays nobody).  HOT = true (the engine saw a barrier with hundreds of events in the
+// previous batch): blocks of 1024 with block-level pre-aggregation.
+constexpr int LINK_BLOCK = 256, LINK_BLOCK_HOT = 1024;
 
-__global__ void __launch_bounds__(LINK_BLOCK) join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n,
-                                                               uint64_t pitch, int32_t* status) {
+template <bool HOT>
+__global__ void __launch_bounds__(HOT ? LINK_BLOCK_HOT : LINK_BLOCK)
+join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t pitch, int32_t* status) {
     // Block-level pre-aggregation for barriers flagged hot: their events are chained inside the block
     // through LDS and the block issues ONE exchange per hot barrier (a contended returning atomic
     // costs ~60 ns, ten thousand of them on one word would serialise the whole pass).
     constexpr int HOT_KEYS = 8, HOT_LIST = 128;
-    __shared__ uint32_t hot_key[HOT_KEYS];               // slot + 1, 0 = free
-    __shared__ uint32_t hot_cnt[HOT_KEYS];
-    __shared__ uint32_t hot_list[HOT_KEYS][HOT_LIST];    // event index + 1
-    __shared__ uint32_t hot_prev[HOT_KEYS];
-    if (threadIdx.x < HOT_KEYS) { hot_key[threadIdx.x] = 0; hot_cnt[threadIdx.x] = 0; }
-    __syncthreads();
+    __shared__ uint32_t hot_key[HOT ? HOT_KEYS : 1];               // slot + 1, 0 = free
+    __shared__ uint32_t hot_cnt[HOT ? HOT_KEYS : 1];
+    __shared__ uint32_t hot_list[HOT ? HOT_KEYS : 1][HOT ? HOT_LIST : 1];    // event index + 1
+    __shared__ uint32_t hot_prev[HOT ? HOT_KEYS : 1];
+    if constexpr (HOT) {
+        if (threadIdx.x < HOT_KEYS) { hot_key[threadIdx.x] = 0; hot_cnt[threadIdx.x] = 0; }
+        __syncthreads();
+    }
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t slot = 0;
     int agg_key = -1;
@@ -165,7 +171,7 @@ __global__ void __launch_bounds__(LINK_BLOCK) join_link_kernel(Table t, Work w, 
             w.dst[i] = dst_pack(info.z, info.x);
             slot = (uint32_t)s;
             w.ev_slot[i] = slot;
-            if (info.y & META_HOT) {
+            if (HOT && (info.y & META_HOT)) {
                 for (int j = 0; j < HOT_KEYS && agg_key < 0; ++j) {
                     const uint32_t k = atomicCAS(&hot_key[j], 0u, slot + 1);
                     if (k == 0 || k == slot + 1) {
@@ -184,6 +190,7 @@ __global__ void __launch_bounds__(LINK_BLOCK) join_link_kernel(Table t, Work w, 
             }
         }
     }
+    if constexpr (!HOT) return;
     __syncthreads();
     if (threadIdx.x < HOT_KEYS && hot_cnt[threadIdx.x] != 0) {
         const uint32_t m = hot_cnt[threadIdx.x] < HOT_LIST ? hot_cnt[threadIdx.x] : HOT_LIST;

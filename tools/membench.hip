@@ -32,6 +32,18 @@ __global__ void rand_rd_kernel(const uint64_t* __restrict__ tab, uint64_t line_m
     if (v == 0x1234567) out[0] = v;          // never true; keeps the load
 }
 
+// two lines per thread: pair = 1 -> both halves of one aligned 128-byte block, pair = 0 -> line and its
+// successor (crosses a 128-byte boundary for odd lines)
+__global__ void rand_rd2_kernel(const uint64_t* __restrict__ tab, uint64_t line_mask, uint32_t n, uint64_t seed,
+                                int pair, uint64_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t line = mix(seed + i) & line_mask;
+    uint64_t other = pair ? (line ^ 1) : ((line + 1) & line_mask);
+    uint64_t v = tab[line * 8], u = tab[other * 8];
+    if (v + u == 0x1234567) out[0] = v;
+}
+
 __global__ void rand_rmw_kernel(uint64_t* __restrict__ tab, uint64_t line_mask, uint32_t n, uint64_t seed) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -84,6 +96,10 @@ int main() {
         printf("table %4zu MiB, %u random 64-byte lines per launch\n", tab_bytes >> 20, n);
         ms = time_ms([&](int r) { rand_rd_kernel<<<n / 256, 256>>>(tab, line_mask, n, 7777ull * r, out); }, 20);
         printf("  rand_rd   : %7.1f us  %.1f G lines/s\n", ms * 1e3, n / ms / 1e6);
+        ms = time_ms([&](int r) { rand_rd2_kernel<<<n / 256, 256>>>(tab, line_mask, n, 7777ull * r, 1, out); }, 20);
+        printf("  rand_rd2 same 128 B : %7.1f us\n", ms * 1e3);
+        ms = time_ms([&](int r) { rand_rd2_kernel<<<n / 256, 256>>>(tab, line_mask, n, 7777ull * r, 0, out); }, 20);
+        printf("  rand_rd2 line, line+1: %7.1f us\n", ms * 1e3);
         ms = time_ms([&](int r) { rand_rmw_kernel<<<n / 256, 256>>>(tab, line_mask, n, 7777ull * r); }, 20);
         printf("  rand_rmw  : %7.1f us  %.1f G lines/s\n", ms * 1e3, n / ms / 1e6);
         ms = time_ms([&](int r) { rand_xchg_kernel<<<n / 256, 256>>>(tab, line_mask, n, 7777ull * r, out); }, 20);
