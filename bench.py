@@ -295,7 +295,8 @@ def main():
         units = {   # algorithmic bytes per launch: per-unit figure x units (kernels table)
             "join_link": (96, batch), "join_resolve": (16, batch), "join_copy": (2 * P, batch),
             "join_complex": (0, 0), "pop": (16, eng.stats()["slots"]), "gather": (96 + 2 * c * P, fired_job / steps_per_job),
-            "fork_claim": (96, nb), "fork_apply": (64, nb), "ack": (128, fired_job / steps_per_job)}
+            "fork_claim": (96, nb), "fork_apply": (64, nb), "ack": (128, fired_job / steps_per_job),
+            "compact": (2 * 72, eng.stats()["slots"])}     # table hygiene: every slot + queue word read and rewritten
         for name, v in acc.items():
             avg = sum(v) / len(v)
             per, n_units = units.get(name, (0, 0))

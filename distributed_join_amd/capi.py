@@ -55,7 +55,7 @@ SYMBOLS = ["dj_create", "dj_destroy", "dj_last_error", "dj_sync", "dj_stream", "
            "dj_queue_scores", "dj_get_stats", "dj_owner_of", "dj_partition_joins", "dj_profile_enable",
            "dj_profile_read", "dj_compact", "dj_set_hot_path"]
 PROF_KERNELS = ["fork_claim", "fork_apply", "join_link", "join_resolve", "join_complex", "join_copy", "pop", "gather",
-                "ack", "recover"]
+                "ack", "recover", "compact"]
 
 _lib = None
 

@@ -39,6 +39,11 @@ struct dj_engine {
     int cx_force;                // -1: automatic, 0 / 1: force the serial / parallel hot-barrier kernels (tests)
     unsigned int* h_maxchain;    // pinned: longest chain of the previous join batch (picks the hot-barrier kernels)
     uint64_t used_upper;         // upper bound of non-empty slots (live + tombstones) since the last compaction
+    // an automatic compaction does not wait for its live count: it arrives in pinned memory
+    // (h_maxchain + 2, 8 bytes) and is picked up by the next fork
+    hipEvent_t compact_ev;
+    bool compact_pending;
+    uint64_t claimed_since_compact;
     int ctr_bank, sweep_bank;    // which half of the double-banked scratch the next call uses
     unsigned int* d_counters;    // 2 x C_COUNT
     unsigned long long* d_sweep; // 2 x S_COUNT
@@ -151,6 +156,7 @@ extern "C" void dj_destroy(dj_engine* e) {
     }
     for (int i = 0; i < e->n_allocs; ++i) (void)hipFree(e->allocs[i]);
     if (e->h_maxchain) (void)hipHostFree(e->h_maxchain);
+    if (e->compact_ev) (void)hipEventDestroy(e->compact_ev);
     delete e;
 }
 
@@ -178,6 +184,9 @@ static int create_impl(dj_engine* e) {
     HIP_TRY(e, hipMemsetAsync(e->slots_alt, 0, slots * sizeof(Slot), e->stream));
     HIP_TRY(e, hipMemsetAsync(e->q_alt, 0xFF, slots * 8, e->stream));
     e->used_upper = 0;
+    e->compact_pending = false;
+    e->claimed_since_compact = 0;
+    HIP_TRY(e, hipEventCreateWithFlags(&e->compact_ev, hipEventDisableTiming));
     ALLOC(e, t.arena, t.arena_units * 64);
     ALLOC(e, t.bump, 8);
     ALLOC(e, t.ring_head, NUM_CLASSES * 4);
@@ -263,6 +272,7 @@ extern "C" int dj_create(const dj_config* cfg, dj_engine** out) {
     e->stream = nullptr;
     e->profiling = 0;
     e->h_maxchain = nullptr;
+    e->compact_ev = nullptr;
     e->cx_force = -1;
     for (int k = 0; k < DJ_PROF_KERNELS; ++k) { e->ev_start[k] = nullptr; e->ev_stop[k] = nullptr; e->ev_used[k] = 0; }
     int rc = create_impl(e);
@@ -324,29 +334,53 @@ static uint32_t scan_blocks(const dj_engine* e) {
 
 // ---- table hygiene ------------------------------------------------------------------------
 // Re-inserts the live barriers into the spare table and swaps: tombstones disappear, probe chains
-// shrink.  Synchronous (reads the live count back).  Outstanding continuations stay valid: their
-// slot hints are verified against the fingerprint before use.
-extern "C" int dj_compact(dj_engine* e, uint64_t* h_live) {
-    if (!e) return DJ_E_INVALID;
-    HIP_TRY(e, hipSetDevice(e->cfg.device));
+// shrink.  Outstanding continuations stay valid: their slot hints are verified against the
+// fingerprint before use.  compact_start queues the work and the read-back of the live count;
+// compact_finish waits for the count (or, with wait = false, takes it only if it has arrived).
+static int compact_start(dj_engine* e) {
     const uint64_t slots = e->t.mask + 1;
     Table to = e->t;
     to.slots = e->slots_alt;
     to.q = e->q_alt;
+    if (e->profiling) (void)hipEventRecord(e->ev_start[DJ_PROF_COMPACT], e->stream);
     HIP_TRY(e, hipMemsetAsync(e->t.stat, 0, 4 * 8, e->stream));
     rebuild_kernel<<<scan_blocks(e), 256, 0, e->stream>>>(e->t, to, e->t.stat);
     HIP_TRY(e, hipGetLastError());
     HIP_TRY(e, hipMemsetAsync(e->t.slots, 0, slots * sizeof(Slot), e->stream));
     HIP_TRY(e, hipMemsetAsync(e->t.q, 0xFF, slots * 8, e->stream));
-    unsigned long long live = 0;
-    HIP_TRY(e, hipMemcpyAsync(&live, e->t.stat, 8, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    if (e->profiling) { (void)hipEventRecord(e->ev_stop[DJ_PROF_COMPACT], e->stream); e->ev_used[DJ_PROF_COMPACT] = 1; }
+    HIP_TRY(e, hipMemcpyAsync(e->h_maxchain + 2, e->t.stat, 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipEventRecord(e->compact_ev, e->stream));
     e->slots_alt = e->t.slots;
     e->q_alt = e->t.q;
     e->t.slots = to.slots;
     e->t.q = to.q;
-    e->used_upper = live;
-    if (h_live) *h_live = live;
+    e->compact_pending = true;
+    e->claimed_since_compact = 0;
+    return DJ_OK;
+}
+
+static int compact_finish(dj_engine* e, bool wait) {
+    if (!e->compact_pending) return DJ_OK;
+    if (wait) HIP_TRY(e, hipEventSynchronize(e->compact_ev));
+    else if (hipEventQuery(e->compact_ev) != hipSuccess) return DJ_OK;
+    unsigned long long live;
+    memcpy(&live, (const void*)(e->h_maxchain + 2), 8);
+    e->used_upper = live + e->claimed_since_compact;
+    e->compact_pending = false;
+    return DJ_OK;
+}
+
+extern "C" int dj_compact(dj_engine* e, uint64_t* h_live) {
+    if (!e) return DJ_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    int rc = compact_finish(e, true);
+    if (rc != DJ_OK) return rc;
+    rc = compact_start(e);
+    if (rc != DJ_OK) return rc;
+    rc = compact_finish(e, true);
+    if (rc != DJ_OK) return rc;
+    if (h_live) *h_live = e->used_upper;
     return DJ_OK;
 }
 
@@ -360,10 +394,20 @@ extern "C" int dj_fork_batch(dj_engine* e, uint32_t n, const dj_fork_rec* d_recs
     // every record may claim a never-used slot; past 80 % non-empty slots lookups of absent keys get
     // long, so sweep the tombstones out first
     if (e->used_upper + n > (e->t.mask + 1) / 5 * 4) {
-        int rc = dj_compact(e, nullptr);
+        // the bound may be stale: a compaction queued by an earlier call reports its live count late
+        int rc = compact_finish(e, true);
         if (rc != DJ_OK) return rc;
+        if (e->used_upper + n > (e->t.mask + 1) / 5 * 4) {
+            // queued on the stream, nobody waits for it; used_upper stays the (now pessimistic) old
+            // bound until the live count is in
+            rc = compact_start(e);
+            if (rc != DJ_OK) return rc;
+        }
+    } else {
+        (void)compact_finish(e, false);
     }
     e->used_upper += n;
+    e->claimed_since_compact += n;
     LAUNCH(e, DJ_PROF_FORK_CLAIM, (fork_claim_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, d_recs, n, d_status)));
     LAUNCH(e, DJ_PROF_FORK_APPLY, (fork_apply_kernel<<<grid_for(n, FORK_APPLY_BLOCK), FORK_APPLY_BLOCK, 0, e->stream>>>(e->t, e->w, d_recs, n, d_status)));
     HIP_TRY(e, hipGetLastError());

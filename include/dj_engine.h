@@ -242,7 +242,7 @@ int dj_set_hot_path(dj_engine* e, int mode);
 enum {
     DJ_PROF_FORK_CLAIM = 0, DJ_PROF_FORK_APPLY, DJ_PROF_JOIN_LINK, DJ_PROF_JOIN_RESOLVE,
     DJ_PROF_JOIN_COMPLEX, DJ_PROF_JOIN_COPY, DJ_PROF_POP, DJ_PROF_GATHER, DJ_PROF_ACK,
-    DJ_PROF_RECOVER, DJ_PROF_KERNELS
+    DJ_PROF_RECOVER, DJ_PROF_COMPACT, DJ_PROF_KERNELS
 };
 int dj_profile_enable(dj_engine* e, int on);
 /* Waits for the stream; h_ms[DJ_PROF_KERNELS] = duration in ms of the most recent launch of
