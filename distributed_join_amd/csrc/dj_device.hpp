@@ -214,8 +214,7 @@ __device__ inline int64_t find_slot(const Table& t, uint64_t lo, uint64_t hi, ui
 }
 
 // Lookup-or-insert for kernels that create slots (fork, retry write-back, orphan queue
-// entries).  Slots only go EMPTY/TOMB -> key inside such a kernel; a plain load that shows a
-// full key is therefore final, a plain load that shows EMPTY/TOMB is re-read atomically.
+// entries).  Slots only go EMPTY/TOMB -> key inside such a kernel, so a key once seen is final.
 // Returns the slot or -1 when the table is full; *created says whether this call claimed it.
 __device__ inline int64_t find_or_claim(const Table& t, uint64_t lo, uint64_t hi, bool* created) {
     *created = false;
@@ -226,8 +225,7 @@ __device__ inline int64_t find_or_claim(const Table& t, uint64_t lo, uint64_t hi
         for (uint64_t p = 0; p <= t.mask && !restart; ++p) {
             const uint64_t s = probe_at(h, p, t.mask);
             Slot* sl = &t.slots[s];
-            uint64_t klo = sl->fp_lo;
-            if (klo == FP_EMPTY || klo == FP_TOMB) klo = a_load(&sl->fp_lo);
+            uint64_t klo = a_load(&sl->fp_lo);       // never from a stale cache line: slots are being claimed
             if (klo == lo) {
                 // same low half: wait (without spinning inside the iteration) for the claimer's
                 // high half, then compare
