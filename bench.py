@@ -193,10 +193,13 @@ def main():
     d_conts = eng.empty(cap_conts * capi.CONT.itemsize)
     d_lens = eng.empty(cap_pos * 4)
     d_pay_out = eng.empty(cap_pos * stride)
-    d_res = eng.empty(16)
+    # one dj_sweep_result (16 bytes) per step: the sweep writes it, the ack reads its n_conts, the host sums
+    # the column after the clock has stopped
+    res_cap = a.warmup + a.steps + 4 * steps_per_job + 8
+    d_res_all = torch.zeros((res_cap, 4), dtype=torch.int32, device=dev)
+    res_i = [0]
     d_status = eng.empty(max(recv_cap, nb * 2) * 4)
     d_ack_status = eng.empty(cap_conts * 4)
-    fired_total = torch.zeros(1, dtype=torch.int64, device=dev)
     es = eng.torch_stream()
 
     router = None
@@ -205,13 +208,13 @@ def main():
         router = Router(eng, dist.group.WORLD, max_send=batch, max_recv=max(recv_cap, nb * 2), pitch=pitch)
 
     now = [1_700_000_000_000]
-    pending = [None]     # routing handle of the NEXT batch, started while the current one is applied
+    pending = []         # routing handles of the next batches (up to two), started while the current one is applied
 
     def start_route(k):
         lo = (k % steps_per_job) * batch
         return router.start(recs[lo:lo + batch], payloads[lo:lo + batch], batch)
 
-    def step(k, prefetch=True):
+    def step(k, prefetch=2):
         """One step: (fork at job start) + join batch + sweep + ack."""
         s = k % steps_per_job
         now[0] += 1
@@ -226,15 +229,22 @@ def main():
         if router is None:
             eng.join_batch_dev(batch, recs[lo:lo + batch], payloads[lo:lo + batch], pitch, now[0], d_status)
         else:
-            h = pending[0] if pending[0] is not None else start_route(k)
+            h = pending.pop(0) if pending else start_route(k)
             r_recs, r_pay, n_in = router.finish(h)
             eng.join_batch_dev(n_in, r_recs, r_pay, pitch, now[0], d_status)
             router.release(h)
-            pending[0] = start_route(k + 1) if prefetch else None
+        d_res = d_res_all[res_i[0] % res_cap]
+        res_i[0] += 1
         eng.sweep_dev(now[0], cap_conts, cap_pos, d_conts, d_lens, None, d_pay_out, d_res)
         eng.ack_batch_dev(cap_conts, d_res, d_conts, None, now[0], d_ack_status)
-        with torch.cuda.stream(es):
-            fired_total.add_(d_res[:4].view(torch.int32)[0].to(torch.int64))
+        if router is not None:
+            # the whole step is queued on the engine's stream; now the host can afford to wait for the
+            # next batch's bucket sizes (the routing runs on the router's stream meanwhile)
+            # (the routing runs on the router's stream meanwhile).  Two batches ahead: the exchange of
+            # batch k+1 was started a step ago, so the engine never waits for the host.
+            for ahead in range(1, prefetch + 1):
+                if len(pending) < ahead:
+                    pending.append(start_route(k + len(pending) + 1))
         if a.hot_frac > 0:
             eng.sync()      # a host that reads each batch's statuses; also lets the engine see the previous
                             # batch's longest chain in time to pick the parallel hot-barrier kernels
@@ -251,22 +261,22 @@ def main():
     # warmup: whole jobs so the timed region starts at a job boundary with an empty table
     warm = (a.warmup + steps_per_job - 1) // steps_per_job * steps_per_job if a.warmup else 0
     for k in range(warm):
-        step(k, prefetch=k + 1 < warm)
+        step(k, prefetch=min(2, warm - 1 - k))
     barrier()
-    fired_total.zero_()
     torch.cuda.synchronize()
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
+    res_first = res_i[0]
     t0 = time.perf_counter()
     ev0.record(es)
     for k in range(a.steps):
-        step(k, prefetch=k + 1 < a.steps)
+        step(k, prefetch=min(2, a.steps - 1 - k))
     ev1.record(es)
     barrier()
     wall = time.perf_counter() - t0
     elapsed = torch.tensor([wall], dtype=torch.float64, device=dev)
-    fired = fired_total.clone()
+    fired = d_res_all[res_first:res_i[0], 0].to(torch.int64).sum().reshape(1)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
         dist.all_reduce(fired)
@@ -281,13 +291,13 @@ def main():
         done = a.steps
         # finish the job in flight so the profiled job starts on an empty table
         while done % steps_per_job:
-            step(done, prefetch=False)
+            step(done, prefetch=0)
             done += 1
         eng.sync()
         eng.profile_enable(True)
         acc = {}
         for k in range(steps_per_job):
-            step(k, prefetch=False)
+            step(k, prefetch=0)
             for name, ms in eng.profile_read().items():
                 acc.setdefault(name, []).append(ms)
         eng.profile_enable(False)

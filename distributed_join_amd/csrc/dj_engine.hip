@@ -642,14 +642,6 @@ extern "C" int dj_get_stats(dj_engine* e, dj_stats* h_stats) {
 }
 
 // ---- multi-GPU routing ------------------------------------------------------------------
-template <int G>
-static void launch_gather_rows(hipStream_t st, const uint8_t* in, uint8_t* out, const uint32_t* origin, uint32_t n, uint64_t pitch) {
-    const uint64_t steps = ((uint64_t)n + (64 / G) - 1) / (64 / G);
-    uint64_t blocks = (steps + 3) / 4;
-    if (blocks > 8192) blocks = 8192;
-    gather_rows_kernel<G><<<(uint32_t)blocks, 256, 0, st>>>(in, out, origin, n, pitch);
-}
-
 extern "C" int dj_partition_joins(dj_engine* e, uint32_t n, uint32_t n_ranks, const dj_join_rec* d_recs,
                                   const uint8_t* d_payloads, uint64_t pitch, dj_join_rec* d_recs_out,
                                   uint8_t* d_payloads_out, uint32_t* d_origin, uint32_t* d_counts, void* stream) {
@@ -670,15 +662,14 @@ extern "C" int dj_partition_joins(dj_engine* e, uint32_t n, uint32_t n_ranks, co
     const uint32_t blocks = grid_for(n, PART_BLOCK);
     partition_count_kernel<<<blocks, PART_BLOCK, 0, st>>>(d_recs, n, n_ranks, scratch);
     partition_scan_kernel<<<1, 1024, 0, st>>>(scratch, blocks, n_ranks, d_counts);
-    partition_scatter_kernel<<<blocks, PART_BLOCK, 0, st>>>(d_recs, n, n_ranks, scratch, d_recs_out, d_origin);
-    if (d_payloads) {
-        const uint64_t lanes = pitch / 16;
-        if (lanes <= 4) launch_gather_rows<4>(st, d_payloads, d_payloads_out, d_origin, n, pitch);
-        else if (lanes <= 8) launch_gather_rows<8>(st, d_payloads, d_payloads_out, d_origin, n, pitch);
-        else if (lanes <= 16) launch_gather_rows<16>(st, d_payloads, d_payloads_out, d_origin, n, pitch);
-        else if (lanes <= 32) launch_gather_rows<32>(st, d_payloads, d_payloads_out, d_origin, n, pitch);
-        else launch_gather_rows<64>(st, d_payloads, d_payloads_out, d_origin, n, pitch);
-    }
+    const uint64_t lanes = d_payloads ? pitch / 16 : 1;
+#define DJ_SCATTER(G) partition_scatter_kernel<G><<<blocks, PART_BLOCK, 0, st>>>(d_recs, n, n_ranks, scratch, d_recs_out, d_origin, d_payloads, d_payloads_out, pitch)
+    if (lanes <= 4) DJ_SCATTER(4);
+    else if (lanes <= 8) DJ_SCATTER(8);
+    else if (lanes <= 16) DJ_SCATTER(16);
+    else if (lanes <= 32) DJ_SCATTER(32);
+    else DJ_SCATTER(64);
+#undef DJ_SCATTER
     HIP_TRY(e, hipGetLastError());
     return DJ_OK;
 }

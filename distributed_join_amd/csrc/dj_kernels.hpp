@@ -1061,10 +1061,15 @@ __global__ void __launch_bounds__(1024) partition_scan_kernel(uint32_t* block_co
     }
 }
 
-// scatter records (and the origin index) to their rank group, keeping array order inside a group
+// scatter records (and the origin index) to their rank group, keeping array order inside a group;
+// the messages follow in the same pass (G lanes per row, 16 bytes per lane, destinations handed
+// from lane to lane inside the wave)
+template <int G>
 __global__ void __launch_bounds__(PART_BLOCK) partition_scatter_kernel(const dj_join_rec* recs, uint32_t n,
                                                                        uint32_t n_ranks, const uint32_t* block_offsets,
-                                                                       dj_join_rec* recs_out, uint32_t* origin) {
+                                                                       dj_join_rec* recs_out, uint32_t* origin,
+                                                                       const uint8_t* pay_in, uint8_t* pay_out,
+                                                                       uint64_t pitch) {
     __shared__ uint32_t wave_cnt[PART_BLOCK / 64][PART_MAX_RANKS];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t i = blockIdx.x * PART_BLOCK + threadIdx.x;
@@ -1082,31 +1087,28 @@ __global__ void __launch_bounds__(PART_BLOCK) partition_scatter_kernel(const dj_
         if (lane == 0) wave_cnt[wv][r] = (uint32_t)__popcll(m);
     }
     __syncthreads();
+    uint32_t o = 0xFFFFFFFFu;
     if (i < n) {
         uint32_t before = 0;
         for (uint32_t v = 0; v < wv; ++v) before += wave_cnt[v][owner];
-        const uint32_t o = block_offsets[blockIdx.x * n_ranks + owner] + before + rank_in_wave;
+        o = block_offsets[blockIdx.x * n_ranks + owner] + before + rank_in_wave;
         reinterpret_cast<ulonglong2*>(recs_out)[2 * (size_t)o] = a;
         reinterpret_cast<ulonglong2*>(recs_out)[2 * (size_t)o + 1] = b;
         origin[o] = i;
     }
-}
-
-// row gather: out row j = in row origin[j]; G lanes per row, 16 bytes per lane
-template <int G>
-__global__ void __launch_bounds__(256) gather_rows_kernel(const uint8_t* in, uint8_t* out, const uint32_t* origin,
-                                                          uint32_t n, uint64_t pitch) {
+    if (pay_in == nullptr) return;
     constexpr int RPW = 64 / G;
-    const uint32_t lane = threadIdx.x & 63, sub = lane / G, j0 = lane % G;
-    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
-    const uint64_t waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const uint32_t sub = lane / G, j0 = lane % G;
     const uint32_t chunks = (uint32_t)(pitch >> 4);
-    for (uint64_t base = wave * RPW; base < n; base += waves * RPW) {
-        const uint64_t j = base + sub;
-        if (j >= n) continue;
-        const uint4* src = reinterpret_cast<const uint4*>(in + (uint64_t)origin[j] * pitch);
-        uint4* dstp = reinterpret_cast<uint4*>(out + j * pitch);
-        for (uint32_t c = j0; c < chunks; c += G) dstp[c] = src[c];
+    const uint32_t wave_i0 = i - lane;
+#pragma unroll 1
+    for (int step = 0; step < G; ++step) {
+        const uint32_t src_lane = step * RPW + sub;
+        const uint32_t oo = __shfl(o, src_lane);
+        if (oo == 0xFFFFFFFFu) continue;
+        const uint4* src = reinterpret_cast<const uint4*>(pay_in + (uint64_t)(wave_i0 + src_lane) * pitch);
+        uint4* dstp = reinterpret_cast<uint4*>(pay_out + (uint64_t)oo * pitch);
+        for (uint32_t c = j0; c < chunks; c += G) nt_store(&dstp[c], nt_load(&src[c]));
     }
 }
 

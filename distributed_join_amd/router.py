@@ -9,9 +9,10 @@ route = partition (HIP kernels, dj_partition_joins: stable, so every owner sees 
 one source in array order) + counts exchange + two all_to_all_single calls (records,
 messages).  The receiver's order is: source rank 0's events, then rank 1's, ...
 
-The router works on its OWN stream with two buffer sets, so the routing of batch k+1 (its
-kernels, its collectives and the host's waits for the bucket sizes) runs while the engine's
-stream applies batch k:
+The router works on its OWN stream with several buffer sets (three by default), so the routing of
+batches k+1 and k+2 (its kernels, its collectives and the host's wait for the bucket sizes) runs
+while the engine's stream applies batch k; with two batches in flight neither stream waits for
+the host:
     h = router.start(recs, payloads, n)     # partition + exchange, asynchronous
     ...                                      # the engine applies the previous batch
     recs_in, pay_in, n_in = router.finish(h) # the engine's stream waits for the data (no host wait)
@@ -36,6 +37,11 @@ def exchange(dist, group, recs_sorted, pay_sorted, send_counts, recv_recs, recv_
     rc = torch.empty(world, dtype=torch.int64, device=recs_sorted.device)
     dist.all_to_all_single(rc, sc, group=group)
     recv_counts = [int(x) for x in rc.cpu().tolist()]
+    return exchange_rows(dist, group, recs_sorted, pay_sorted, send_counts, recv_counts, recv_recs, recv_pay)
+
+
+def exchange_rows(dist, group, recs_sorted, pay_sorted, send_counts, recv_counts, recv_recs, recv_pay):
+    """The data part of exchange(): both sides' bucket sizes are known."""
     n_in, n_out = sum(recv_counts), sum(send_counts)
     if n_in > recv_recs.shape[0]:
         raise RuntimeError(f"router: {n_in} incoming records exceed the receive buffer ({recv_recs.shape[0]})")
@@ -48,13 +54,15 @@ def exchange(dist, group, recs_sorted, pay_sorted, send_counts, recv_recs, recv_
 
 
 class _Slot:
-    """One of the two buffer sets."""
+    """One buffer set."""
 
     def __init__(self, torch, dev, max_send, max_recv, pitch):
         self.recs_sorted = torch.empty((max_send, 4), dtype=torch.int64, device=dev)
         self.pay_sorted = torch.empty((max_send, pitch), dtype=torch.uint8, device=dev)
         self.origin = torch.empty(max_send, dtype=torch.int32, device=dev)
         self.counts = torch.empty(64, dtype=torch.int32, device=dev)
+        self.counts_in = torch.empty(64, dtype=torch.int32, device=dev)
+        self.h_counts = torch.empty(128, dtype=torch.int32).pin_memory()   # [0:64] sent, [64:128] received
         self.recv_recs = torch.empty((max_recv, 4), dtype=torch.int64, device=dev)
         self.recv_pay = torch.empty((max_recv, pitch), dtype=torch.uint8, device=dev)
         self.ready = torch.cuda.Event()      # data has arrived (recorded on the router's stream)
@@ -65,7 +73,7 @@ class _Slot:
 
 
 class Router:
-    def __init__(self, engine, group, max_send, max_recv, pitch):
+    def __init__(self, engine, group, max_send, max_recv, pitch, depth=3):
         import torch
         import torch.distributed as dist
         self.torch = torch
@@ -75,7 +83,7 @@ class Router:
         dev = engine.device
         self.stream = torch.cuda.Stream(device=dev)
         self.engine_stream = engine.torch_stream()
-        self.slots = [_Slot(torch, dev, max_send, max_recv, self.pitch) for _ in range(2)]
+        self.slots = [_Slot(torch, dev, max_send, max_recv, self.pitch) for _ in range(max(2, int(depth)))]
         self.turn = 0
 
     def start(self, d_recs, d_payloads, n):
@@ -84,7 +92,7 @@ class Router:
         device.  Returns a handle for finish()."""
         torch = self.torch
         s = self.slots[self.turn]
-        self.turn ^= 1
+        self.turn = (self.turn + 1) % len(self.slots)
         with torch.cuda.stream(self.stream):
             if s.free_pending:                    # the engine may still be reading this buffer set
                 self.stream.wait_event(s.free)
@@ -93,9 +101,15 @@ class Router:
             self.e.partition_joins_dev(n, self.world, d_recs, d_payloads, self.pitch, s.recs_sorted,
                                        s.pay_sorted if s.has_pay else None, s.origin, s.counts,
                                        stream_ptr=self.stream.cuda_stream)
-            send_counts = [int(x) for x in s.counts[:self.world].cpu().tolist()]   # waits for the router's stream only
-            s.n_in, _ = exchange(self.dist, self.group, s.recs_sorted, s.pay_sorted if s.has_pay else None,
-                                 send_counts, s.recv_recs, s.recv_pay)
+            # bucket sizes travel rank to rank on the device; ONE read-back brings both sides' sizes to the host
+            w = self.world
+            self.dist.all_to_all_single(s.counts_in[:w], s.counts[:w], group=self.group)
+            s.h_counts[:64].copy_(s.counts, non_blocking=True)
+            s.h_counts[64:].copy_(s.counts_in, non_blocking=True)
+            self.stream.synchronize()                 # waits for the router's stream only
+            hc = s.h_counts.tolist()
+            s.n_in, _ = exchange_rows(self.dist, self.group, s.recs_sorted, s.pay_sorted if s.has_pay else None,
+                                      hc[:w], hc[64:64 + w], s.recv_recs, s.recv_pay)
             s.ready.record(self.stream)
         return s
 
