@@ -17,7 +17,7 @@ DJ_E_INVALID, DJ_E_HIP, DJ_E_NOMEM, DJ_E_CLOCK_RANGE, DJ_E_TOO_LARGE = -1, -2, -
 DJ_NIL = 0xFFFFFFFF
 DJ_NOT_QUEUED = 0xFFFFFFFFFFFFFFFF
 DJ_JOIN_WAITING, DJ_JOIN_COMPLETE, DJ_JOIN_NOT_FOUND = 1, 2, 3
-DJ_JOIN_BAD_POSITION, DJ_JOIN_NEAREST_NOT_QUEUED, DJ_JOIN_TOO_LONG = 4, 5, 6
+DJ_JOIN_BAD_POSITION, DJ_JOIN_NEAREST_NOT_QUEUED, DJ_JOIN_TOO_LONG, DJ_JOIN_BAD_MAX_WAIT = 4, 5, 6, 7
 DJ_FORK_CREATED, DJ_FORK_TABLE_FULL, DJ_FORK_NO_SPACE, DJ_FORK_BAD_COUNT = 1, 2, 3, 4
 DJ_ACK_DONE, DJ_ACK_REQUEUED_DIRTY, DJ_ACK_RETRY = 1, 2, 3
 DJ_ACK_DROPPED_EXHAUSTED, DJ_ACK_DONE_NO_METADATA = 4, 5

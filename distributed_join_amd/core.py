@@ -63,6 +63,8 @@ class ForkJoinService:
             return BAD_REQUEST, "position is greater than total"
         if st == capi.DJ_JOIN_TOO_LONG:
             return BAD_REQUEST, f"Message length cannot exceed {self.env['join-message-len-max']}"
+        if st == capi.DJ_JOIN_BAD_MAX_WAIT:     # unreachable behind validate_join (store.clj:27-28), kept for direct callers
+            return BAD_REQUEST, f"max-wait must be positive and less than or equal to {self.env['join-max-wait']}"
         return INTERNAL_ERROR, "Database failure(s)"                              # redis.clj:17-21
 
     # core/status, core.clj:60-68 (+ the length guard of ring.clj:78-79)

@@ -448,7 +448,8 @@ __device__ inline uint8_t* slab_payload(const Table& t, uint32_t slab, uint32_t 
     return t.arena + (uint64_t)slab * 64 + slab_payload_off(k);
 }
 
-// node packing of the join link pass
+// node packing of the join link pass: next (25) | position (10) | max-wait (29)
+constexpr uint32_t NODE_MW_LIMIT = 1u << 29;
 __device__ inline uint64_t node_pack(uint32_t next, uint32_t pos, uint32_t mw) {
     return (uint64_t)next | ((uint64_t)pos << 25) | ((uint64_t)mw << 35);
 }

@@ -155,6 +155,8 @@ join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t 
         uint4 info = make_uint4(0, 0, 0, 0);               // count, meta, slab, chain of the slot
         if (b.y > t.stride || b.y > pitch) {
             st = DJ_JOIN_TOO_LONG;                         // store.clj:24-26
+        } else if (b.z >= NODE_MW_LIMIT) {
+            st = DJ_JOIN_BAD_MAX_WAIT;                     // engine limit (store.clj:27 caps it far lower)
         } else {
             s = find_slot(t, a.x, a.y, &info);
             if (s < 0 || !(info.y & META_HAS) || info.z == 0) st = DJ_JOIN_NOT_FOUND;   // redis.clj:152

@@ -62,6 +62,8 @@ typedef struct dj_engine dj_engine;
                                           the position was already stored                           */
 #define DJ_JOIN_TOO_LONG            6  /* 400: message longer than dj_config.payload_stride
                                           (store.clj:24-26 with the engine's own limit)             */
+#define DJ_JOIN_BAD_MAX_WAIT        7  /* 400: max_wait_s >= 2^29 (store.clj:27-28 with the engine's own
+                                          limit; the reference's configured limits are 500..6000 s)  */
 /* dj_fork_batch: core/fork (core.clj:24-33) */
 #define DJ_FORK_CREATED             1  /* 201, barrier created or fully reset (redis.clj:90-104)    */
 #define DJ_FORK_TABLE_FULL          2  /* engine limit: no free table slot                          */

@@ -346,3 +346,21 @@ def test_compaction_under_key_churn(oracle_lib):
         d.check_all_snapshots(range(0, len(ids), 13))
     finally:
         e.close()
+
+
+def test_max_wait_beyond_the_engine_limit_is_refused():
+    """A max-wait that does not fit the link word (>= 2^29 s, ~17 years) is answered with its own
+    status and leaves the barrier untouched; the largest accepted value behaves like any other."""
+    e = _engine(capacity_barriers=64, arena_bytes=1 << 20, max_count=4, payload_stride=64, max_batch=64)
+    lo, hi = capi.fingerprint("j1~t1")
+    fk = np.zeros(1, dtype=capi.FORK_REC)
+    fk[0] = (lo, hi, 2, 0, T0 + 5000)
+    assert e.fork_batch(fk).tolist() == [capi.DJ_FORK_CREATED]
+    recs = np.zeros(2, dtype=capi.JOIN_REC)
+    recs[0] = (lo, hi, 0, 3, 1 << 29, 0)
+    recs[1] = (lo, hi, 1, 3, (1 << 29) - 1, 0)
+    st = e.join_batch(recs, np.zeros((2, 64), np.uint8), T0 + 1)
+    assert st.tolist() == [capi.DJ_JOIN_BAD_MAX_WAIT, capi.DJ_JOIN_WAITING]
+    meta, lens, mws, _ = e.snapshot_one(lo, hi)
+    assert lens.tolist()[:2] == [capi.DJ_NIL, 3] and mws.tolist()[1] == (1 << 29) - 1
+    e.close()
