@@ -185,7 +185,8 @@ def main():
     # ---- engine ------------------------------------------------------------------------------
     slab_bytes = 64 * (1 + (8 * (1 << (c - 1).bit_length()) + 63) // 64) + (1 << (c - 1).bit_length()) * stride
     recv_cap = batch if world == 1 else int(batch * 1.25) + 4096       # hash imbalance headroom
-    eng = Engine(capacity_barriers=nb if world == 1 else int(nb * 1.25) + 1024,
+    # capacity nb -> 2 * nb slots at every N (a rank owns nb +- 0.3 % of the global barrier space)
+    eng = Engine(capacity_barriers=nb,
                  arena_bytes=int(nb * (1.0 if world == 1 else 1.3) * (slab_bytes + 64)) + (64 << 20), max_count=c,
                  payload_stride=stride, max_batch=max(recv_cap, nb * 2 if world > 1 else nb), device=local)
     cap_conts = int(nb * (1.0 if world == 1 else 1.3)) + 1024
