@@ -53,7 +53,7 @@ SYMBOLS = ["dj_create", "dj_destroy", "dj_last_error", "dj_sync", "dj_stream", "
            "dj_fingerprint_batch", "dj_fork_batch", "dj_join_batch", "dj_pop_due", "dj_sweep",
            "dj_ack_batch", "dj_recover", "dj_snapshot_one", "dj_store_in_publish_queue",
            "dj_queue_scores", "dj_get_stats", "dj_owner_of", "dj_partition_joins", "dj_profile_enable",
-           "dj_profile_read", "dj_compact", "dj_set_hot_path"]
+           "dj_profile_read", "dj_compact", "dj_set_hot_path", "dj_checkpoint_save", "dj_checkpoint_load"]
 PROF_KERNELS = ["fork_claim", "fork_apply", "join_link", "join_resolve", "join_complex", "join_copy", "pop", "gather",
                 "ack", "recover", "compact"]
 
@@ -117,6 +117,10 @@ def load():
     L.dj_partition_joins.argtypes = [vp, u32, u32, vp, vp, u64, vp, vp, vp, vp, vp]
     L.dj_set_hot_path.restype = i32
     L.dj_set_hot_path.argtypes = [vp, i32]
+    L.dj_checkpoint_save.restype = i32
+    L.dj_checkpoint_save.argtypes = [vp, ctypes.c_char_p]
+    L.dj_checkpoint_load.restype = i32
+    L.dj_checkpoint_load.argtypes = [vp, ctypes.c_char_p]
     L.dj_compact.restype = i32
     L.dj_compact.argtypes = [vp, ctypes.POINTER(u64)]
     L.dj_profile_enable.restype = i32

@@ -7,6 +7,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -638,6 +639,132 @@ extern "C" int dj_get_stats(dj_engine* e, dj_stats* h_stats) {
     h_stats->arena_units_free = 0;
     for (uint32_t k = 0; k < NUM_CLASSES; ++k)
         h_stats->arena_units_free += (uint64_t)(tail[k] - head[k]) * slab_units(k, e->t.stride);
+    return DJ_OK;
+}
+
+// ---- durability -----------------------------------------------------------------------------
+namespace {
+struct CkptHeader {
+    char magic[8];               // "DJCKPT1\0"
+    uint64_t slots, arena_units_used, arena_units_total;
+    uint32_t stride, max_count;
+    uint32_t ring_n[NUM_CLASSES];    // free slabs per class, stored head-first after the arena
+    uint64_t used_upper;
+};
+const size_t CKPT_CHUNK = 64u << 20;
+
+int dev_to_file(dj_engine* e, FILE* f, const void* dev, size_t bytes, void* stage) {
+    const uint8_t* p = static_cast<const uint8_t*>(dev);
+    for (size_t off = 0; off < bytes; off += CKPT_CHUNK) {
+        const size_t m = bytes - off < CKPT_CHUNK ? bytes - off : CKPT_CHUNK;
+        HIP_TRY(e, hipMemcpy(stage, p + off, m, hipMemcpyDeviceToHost));
+        if (fwrite(stage, 1, m, f) != m) return fail(e, DJ_E_INVALID, "checkpoint: short write");
+    }
+    return DJ_OK;
+}
+
+int file_to_dev(dj_engine* e, FILE* f, void* dev, size_t bytes, void* stage) {
+    uint8_t* p = static_cast<uint8_t*>(dev);
+    for (size_t off = 0; off < bytes; off += CKPT_CHUNK) {
+        const size_t m = bytes - off < CKPT_CHUNK ? bytes - off : CKPT_CHUNK;
+        if (fread(stage, 1, m, f) != m) return fail(e, DJ_E_INVALID, "checkpoint: file is truncated");
+        HIP_TRY(e, hipMemcpy(p + off, stage, m, hipMemcpyHostToDevice));
+    }
+    return DJ_OK;
+}
+}  // namespace
+
+extern "C" int dj_checkpoint_save(dj_engine* e, const char* path) {
+    if (!e || !path) return DJ_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    int rc = compact_finish(e, true);
+    if (rc != DJ_OK) return rc;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    CkptHeader h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, "DJCKPT1", 8);
+    h.slots = e->t.mask + 1;
+    h.arena_units_total = e->t.arena_units;
+    h.stride = e->t.stride;
+    h.max_count = e->t.max_count;
+    h.used_upper = e->used_upper;
+    unsigned long long bump;
+    unsigned int head[NUM_CLASSES], tail[NUM_CLASSES];
+    HIP_TRY(e, hipMemcpy(&bump, e->t.bump, 8, hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(head, e->t.ring_head, sizeof head, hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(tail, e->t.ring_tail, sizeof tail, hipMemcpyDeviceToHost));
+    h.arena_units_used = bump < e->t.arena_units ? bump : e->t.arena_units;
+    for (uint32_t k = 0; k < NUM_CLASSES; ++k) h.ring_n[k] = tail[k] - head[k];
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(e, DJ_E_INVALID, "checkpoint: cannot open %s for writing", path);
+    void* stage = malloc(CKPT_CHUNK);
+    if (!stage) { fclose(f); return fail(e, DJ_E_NOMEM, "checkpoint: no staging memory"); }
+    rc = fwrite(&h, sizeof h, 1, f) == 1 ? DJ_OK : fail(e, DJ_E_INVALID, "checkpoint: short write");
+    if (rc == DJ_OK) rc = dev_to_file(e, f, e->t.slots, h.slots * sizeof(Slot), stage);
+    if (rc == DJ_OK) rc = dev_to_file(e, f, e->t.q, h.slots * 8, stage);
+    if (rc == DJ_OK) rc = dev_to_file(e, f, e->t.arena, h.arena_units_used * 64, stage);
+    for (uint32_t k = 0; k < NUM_CLASSES && rc == DJ_OK; ++k) {
+        // the ring's live window [head, tail) may wrap: two pieces, head-first
+        const uint32_t cap = e->t.ring_cap[k], n = h.ring_n[k], at = head[k] & (cap - 1);
+        const uint32_t first = n < cap - at ? n : cap - at;
+        rc = dev_to_file(e, f, e->t.ring[k] + at, (size_t)first * 4, stage);
+        if (rc == DJ_OK) rc = dev_to_file(e, f, e->t.ring[k], (size_t)(n - first) * 4, stage);
+    }
+    free(stage);
+    if (fclose(f) != 0 && rc == DJ_OK) rc = fail(e, DJ_E_INVALID, "checkpoint: close failed");
+    return rc;
+}
+
+extern "C" int dj_checkpoint_load(dj_engine* e, const char* path) {
+    if (!e || !path) return DJ_E_INVALID;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    int rc = compact_finish(e, true);
+    if (rc != DJ_OK) return rc;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(e, DJ_E_INVALID, "checkpoint: cannot open %s", path);
+    CkptHeader h;
+    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "DJCKPT1", 8) != 0) {
+        fclose(f);
+        return fail(e, DJ_E_INVALID, "checkpoint: %s is not a checkpoint file", path);
+    }
+    if (h.slots != e->t.mask + 1 || h.stride != e->t.stride || h.max_count != e->t.max_count ||
+        h.arena_units_used > e->t.arena_units) {
+        fclose(f);
+        return fail(e, DJ_E_INVALID, "checkpoint: saved with slots=%llu stride=%u max_count=%u arena_used=%llu units, "
+                    "engine has slots=%llu stride=%u max_count=%u arena=%llu units",
+                    (unsigned long long)h.slots, h.stride, h.max_count, (unsigned long long)h.arena_units_used,
+                    (unsigned long long)(e->t.mask + 1), e->t.stride, e->t.max_count, (unsigned long long)e->t.arena_units);
+    }
+    for (uint32_t k = 0; k < NUM_CLASSES; ++k)
+        if (h.ring_n[k] > e->t.ring_cap[k]) {
+            fclose(f);
+            return fail(e, DJ_E_INVALID, "checkpoint: free list of class %u does not fit", k);
+        }
+    void* stage = malloc(CKPT_CHUNK);
+    if (!stage) { fclose(f); return fail(e, DJ_E_NOMEM, "checkpoint: no staging memory"); }
+    rc = file_to_dev(e, f, e->t.slots, h.slots * sizeof(Slot), stage);
+    if (rc == DJ_OK) rc = file_to_dev(e, f, e->t.q, h.slots * 8, stage);
+    if (rc == DJ_OK) rc = file_to_dev(e, f, e->t.arena, h.arena_units_used * 64, stage);
+    unsigned int head[NUM_CLASSES], tail[NUM_CLASSES];
+    for (uint32_t k = 0; k < NUM_CLASSES && rc == DJ_OK; ++k) {
+        rc = file_to_dev(e, f, e->t.ring[k], (size_t)h.ring_n[k] * 4, stage);
+        head[k] = 0;
+        tail[k] = h.ring_n[k];
+    }
+    free(stage);
+    fclose(f);
+    if (rc != DJ_OK) return rc;      // the engine's state is undefined after a failed load of a valid header
+    const unsigned long long bump = h.arena_units_used;
+    HIP_TRY(e, hipMemcpy(e->t.bump, &bump, 8, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->t.ring_head, head, sizeof head, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->t.ring_tail, tail, sizeof tail, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->t.ring_tail_snap, tail, sizeof tail, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemset(e->d_counters, 0, 2 * C_COUNT * 4));
+    HIP_TRY(e, hipMemset(e->d_sweep, 0, 2 * S_COUNT * 8));
+    e->used_upper = h.used_upper;
+    e->claimed_since_compact = 0;
+    *e->h_maxchain = 0;
     return DJ_OK;
 }
 

@@ -236,6 +236,14 @@ class Engine:
         """-1 automatic, 0 serial, 1 parallel kernels for barriers with long chains (same results)."""
         self._check(self.L.dj_set_hot_path(self.h, int(mode)))
 
+    def checkpoint_save(self, path):
+        """Write the whole barrier state to a file (waits for the stream)."""
+        self._check(self.L.dj_checkpoint_save(self.h, str(path).encode()))
+
+    def checkpoint_load(self, path):
+        """Replace this engine's state with a saved one (same capacity, stride and max_count)."""
+        self._check(self.L.dj_checkpoint_load(self.h, str(path).encode()))
+
     def compact(self):
         """Rehash the live barriers into the spare table (drops tombstones); returns the live count."""
         live = ctypes.c_uint64(0)

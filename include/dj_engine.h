@@ -228,9 +228,20 @@ int dj_get_stats(dj_engine* e, dj_stats* h_stats);
 
 /* Table hygiene, no counterpart in the reference (Redis reclaims deleted keys itself): re-inserts
  * the live barriers into a spare table so that the tombstones of deleted barriers stop lengthening
- * lookups.  dj_fork_batch calls it by itself when the table may be more than 80 % non-empty;
- * synchronous.  *h_live (optional) = live slots. */
+ * lookups.  dj_fork_batch queues the same work on the stream by itself (without waiting) when the
+ * table may be more than 80 % non-empty; this call waits.  *h_live (optional) = live slots. */
 int dj_compact(dj_engine* e, uint64_t* h_live);
+
+/* Durability.  The reference keeps all of this state in Redis and inherits Redis' persistence
+ * (RDB / AOF; the service itself only holds a connection, redis.clj:13-15).  dj_checkpoint_save
+ * waits for the stream and writes the whole barrier state (table, queue words, the used part of the
+ * message arena, free lists) to a file; dj_checkpoint_load replaces the state of an engine created
+ * with the same capacity_barriers, payload_stride and max_count (and an arena at least as large as
+ * the saved one's used part) with the file's.  Outstanding continuations of the saved engine stay
+ * valid on the restored one.  Both are synchronous and meant for quiet moments (shutdown, start,
+ * periodic snapshots between batches). */
+int dj_checkpoint_save(dj_engine* e, const char* path);
+int dj_checkpoint_load(dj_engine* e, const char* path);
 
 /* Barriers that receive very many events in one batch (hot keys, replays) are resolved by a
  * parallel set of kernels instead of a serial walk; the engine switches by itself from the longest

@@ -27,8 +27,9 @@ def make_pair(oracle_lib, ids, stride, max_count=999, capacity=None, arena=256 <
     return e, o, ParityDriver(e, o, ids)
 
 
-def run_oplog(d, rng, n_barriers, counts, stride, rounds, batch, hot=None, var_len=False, unknown=0):
-    """counts[b] is fixed per barrier index (a re-fork keeps it)."""
+def run_oplog(d, rng, n_barriers, counts, stride, rounds, batch, hot=None, var_len=False, unknown=0, on_round=None):
+    """counts[b] is fixed per barrier index (a re-fork keeps it).  on_round(r) runs after round r
+    (continuations may be in flight at that moment)."""
     now = T0
     forked = np.zeros(n_barriers, dtype=bool)
     version = 0
@@ -69,6 +70,8 @@ def run_oplog(d, rng, n_barriers, counts, stride, rounds, batch, hot=None, var_l
         if rng.random() < 0.5:
             now += int(rng.integers(0, 3000))
             d.recover(now)
+        if on_round is not None:
+            on_round(r)
     while inflight:
         ec, oc = inflight.pop(0)
         d.ack(ec, oc, lambda k: True, now)
@@ -168,3 +171,52 @@ def test_config2_shape_scaled(oracle_lib):
         assert e.stats()["live"] == 0 and o.live_barriers() == 0
     finally:
         e.close()
+
+
+def test_checkpoint_restore_mid_oplog(oracle_lib, tmp_path):
+    """Every third round the engine is saved to a file, destroyed, and a NEW engine restored from the
+    file carries on (with continuations in flight, tombstones, freed slabs and retry counters in the
+    table); the oracle runs through uninterrupted.  Everything must stay bit-exact."""
+    from distributed_join_amd.engine import Engine
+    rng = np.random.default_rng(77)
+    nb, stride = 300, 64
+    ids = [f"ck{b:x}~t{b % 7}" for b in range(nb)]
+    counts = rng.integers(1, 80, nb)          # includes multi-word bitmaps (count > 64)
+    kw = dict(capacity_barriers=nb, arena_bytes=64 << 20, max_count=999, payload_stride=stride, max_batch=1 << 16,
+              check_publish_delay_ms=2000, host_cap_conts=1 << 16, host_cap_positions=1 << 20)
+    e, o, d = make_pair(oracle_lib, ids, stride, capacity=nb, arena=64 << 20)
+    path = tmp_path / "engine.ckpt"
+    swaps = []
+
+    def swap(r):
+        if r % 3 != 2:
+            return
+        d.e.checkpoint_save(path)
+        before = d.e.stats()
+        d.e.close()
+        d.e = Engine(**kw)
+        d.e.checkpoint_load(path)
+        assert d.e.stats() == before
+        swaps.append(r)
+
+    run_oplog(d, rng, nb, counts, stride, rounds=14, batch=500, on_round=swap)
+    assert len(swaps) == 4
+    d.e.close()
+
+
+def test_checkpoint_load_rejects_other_geometry(tmp_path):
+    from distributed_join_amd.engine import Engine
+    a = Engine(capacity_barriers=64, arena_bytes=1 << 20, max_count=8, payload_stride=64, max_batch=64)
+    path = tmp_path / "a.ckpt"
+    a.checkpoint_save(path)
+    a.close()
+    b = Engine(capacity_barriers=64, arena_bytes=1 << 20, max_count=8, payload_stride=128, max_batch=64)
+    with pytest.raises(RuntimeError, match="checkpoint"):
+        b.checkpoint_load(path)
+    with pytest.raises(RuntimeError, match="checkpoint"):
+        b.checkpoint_load(tmp_path / "missing.ckpt")
+    junk = tmp_path / "junk.ckpt"
+    junk.write_bytes(b"not a checkpoint" * 100)
+    with pytest.raises(RuntimeError, match="checkpoint"):
+        b.checkpoint_load(junk)
+    b.close()
