@@ -245,15 +245,16 @@ __global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     bool is_complex = false;
     uint32_t s = tid < n ? w.ev_slot[tid] : 0xFFFFFFFFu;
+    // The event that linked FIRST (it found the chain empty) resolves the barrier: it knows that from
+    // its own link word, so every other event leaves without touching the table again.
+    if (s != 0xFFFFFFFFu && node_next(w.node[tid]) != 0) s = 0xFFFFFFFFu;
     uint4 info = make_uint4(0, 0, 0, 0);
     uint64_t bits0 = 0;
     if (s != 0xFFFFFFFFu) {
         info = reinterpret_cast<const uint4*>(&t.slots[s])[1];   // count, meta, slab, chain
         bits0 = t.slots[s].bits;                                 // requested with it: one round trip
     }
-    // The event at the head of a barrier's chain (the last one linked) resolves the barrier; every
-    // other event of the chain sees another index (or 0 once the head is done) and leaves.
-    if (s != 0xFFFFFFFFu && info.w == tid + 1) {
+    if (s != 0xFFFFFFFFu) {
         Slot* sl = &t.slots[s];
         const uint32_t count = info.x, slab = info.z;
         uint32_t cur = info.w;
