@@ -493,7 +493,7 @@ static void dispatch_gather(dj_engine* e, const dj_cont* conts, int from_sweep, 
                             dj_sweep_result* res) {
     // lanes per continuation from the largest continuation the engine can hold (16-byte chunks)
     const uint64_t items = (uint64_t)e->cfg.max_count * (e->cfg.payload_stride / 16);
-    if (items <= 64) launch_gather<8>(e, conts, from_sweep, n_fixed, cap_conts, cap_pos, update_ts, lens, mws, payloads, res);
+    if (items <= 16) launch_gather<8>(e, conts, from_sweep, n_fixed, cap_conts, cap_pos, update_ts, lens, mws, payloads, res);
     else if (items <= 512) launch_gather<16>(e, conts, from_sweep, n_fixed, cap_conts, cap_pos, update_ts, lens, mws, payloads, res);
     else launch_gather<64>(e, conts, from_sweep, n_fixed, cap_conts, cap_pos, update_ts, lens, mws, payloads, res);
 }
