@@ -364,3 +364,85 @@ def test_max_wait_beyond_the_engine_limit_is_refused():
     meta, lens, mws, _ = e.snapshot_one(lo, hi)
     assert lens.tolist()[:2] == [capi.DJ_NIL, 3] and mws.tolist()[1] == (1 << 29) - 1
     e.close()
+
+
+def test_config4_one_rank_share_scaled():
+    """BASELINE config #4's shape (count 16, 256 B messages, events generated for the whole barrier
+    space, owner = hash mod 8, routed by partition) from the point of view of ONE of the 8 ranks,
+    scaled to 2^18 global barriers: every batch goes through the 8-way partition kernels, the rank
+    applies its own bucket straight from the partition's output buffers.  Its barriers (and only
+    they) fire exactly once, complete, with every byte where the generator put it."""
+    import torch
+    from distributed_join_amd.router import owner_of_np
+    nbg, c, P, ranks, me = 1 << 18, 16, 256, 8, 3
+    rng = np.random.default_rng(44)
+    ids = [f"job{b % 1000}~tx{b:x}" for b in range(nbg)]
+    fps = capi.fingerprint_many(ids)
+    owner = owner_of_np(fps[:, 1], ranks)
+    mine = np.nonzero(owner == me)[0]
+    nb = len(mine)
+    assert abs(nb - nbg / ranks) < 0.05 * nbg / ranks            # the hash spreads the barriers evenly
+    batch = 1 << 18
+    e = _engine(capacity_barriers=nb, arena_bytes=nb * (16 * P + 256) + (64 << 20), max_count=c, payload_stride=P,
+                max_batch=batch)
+    dev = e.device
+    try:
+        frecs = np.zeros(nb, dtype=capi.FORK_REC)
+        frecs["fp_lo"], frecs["fp_hi"], frecs["count"], frecs["deadline_ms"] = fps[mine, 0], fps[mine, 1], c, T0 + 3_600_000
+        assert (e.fork_batch(frecs) == capi.DJ_FORK_CREATED).all()
+        ev = rng.permutation(nbg * c)
+        d_ro = torch.empty(batch * 32, dtype=torch.uint8, device=dev)
+        d_po = torch.empty((batch, P), dtype=torch.uint8, device=dev)
+        d_origin = torch.empty(batch, dtype=torch.int32, device=dev)
+        d_counts = torch.zeros(64, dtype=torch.int32, device=dev)
+        d_st = e.empty(batch * 4)
+        cap_c, cap_p = nb, nb * c
+        d_conts, d_lens, d_pay, d_res, d_ack = e.empty(cap_c * 64), e.empty(cap_p * 4), e.empty(cap_p * P), e.empty(16), e.empty(cap_c * 4)
+        pos_of = {int(b): k for k, b in enumerate(mine)}
+        by_fp = {(int(a), int(b)): int(g) for g, (a, b) in zip(mine, fps[mine])}
+        fired = np.zeros(nb, dtype=np.int32)
+        applied = 0
+        for k in range(nbg * c // batch):
+            now = T0 + 1 + k
+            part = ev[k * batch:(k + 1) * batch]
+            jb, jp = part // c, part % c
+            recs = np.zeros(batch, dtype=capi.JOIN_REC)
+            recs["fp_lo"], recs["fp_hi"], recs["position"], recs["len"] = fps[jb, 0], fps[jb, 1], jp, P
+            d_recs = torch.from_numpy(recs.view(np.uint8).reshape(-1).copy()).to(dev)
+            d_in = torch.from_numpy(payload_bytes(jb, jp, jb * 0, P)).to(dev)
+            torch.cuda.synchronize()
+            e.partition_joins_dev(batch, ranks, d_recs, d_in, P, d_ro, d_po, d_origin, d_counts)
+            e.sync()
+            counts = d_counts.cpu().numpy()[:ranks]
+            np.testing.assert_array_equal(counts, np.bincount(owner[jb], minlength=ranks))
+            lo, n_me = int(counts[:me].sum()), int(counts[me])
+            applied += n_me
+            if n_me:
+                e.join_batch_dev(n_me, d_ro[lo * 32:], d_po[lo:], P, now, d_st)
+                e.sync()
+                st = d_st[:n_me * 4].cpu().numpy().view(np.int32)
+                assert np.isin(st, [capi.DJ_JOIN_WAITING, capi.DJ_JOIN_COMPLETE]).all()
+            res = np.zeros(1, dtype=capi.SWEEP_RESULT)
+            e.sweep_dev(now, cap_c, cap_p, d_conts, d_lens, None, d_pay, d_res, res)
+            n, npos = int(res[0]["n_conts"]), int(res[0]["n_positions"])
+            assert not res[0]["more"] and npos == n * c
+            if n == 0:
+                continue
+            conts = d_conts[:n * 64].cpu().numpy().view(capi.CONT)
+            assert (conts["flags"] == 0).all() and (conts["count"] == c).all()
+            gidx = np.array([by_fp[(int(a), int(b))] for a, b in zip(conts["fp_lo"], conts["fp_hi"])])
+            np.add.at(fired, [pos_of[int(g)] for g in gidx], 1)
+            assert (d_lens[:npos * 4].cpu().numpy().view(np.uint32) == P).all()
+            got = d_pay[:npos * P].cpu().numpy().reshape(npos, P)
+            rows = (conts["pos_base"].astype(np.int64)[:, None] + np.arange(c)[None, :]).reshape(-1)
+            want = payload_bytes(np.repeat(gidx, c), np.tile(np.arange(c), n), np.zeros(n * c), P)
+            assert np.array_equal(got[rows], want), "a gathered byte differs from the generator"
+            e.ack_batch_dev(n, None, d_conts, None, now, d_ack)
+            e.sync()
+            assert (d_ack[:n * 4].cpu().numpy().view(np.int32) == capi.DJ_ACK_DONE).all()
+        assert applied == nb * c
+        assert (fired == 1).all()
+        s = e.stats()
+        assert s["live"] == 0 and s["tombstones"] == nb
+    finally:
+        e.close()
