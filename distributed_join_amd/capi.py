@@ -53,7 +53,25 @@ SYMBOLS = ["dj_create", "dj_destroy", "dj_last_error", "dj_sync", "dj_stream", "
            "dj_fingerprint_batch", "dj_fork_batch", "dj_join_batch", "dj_pop_due", "dj_sweep",
            "dj_ack_batch", "dj_recover", "dj_snapshot_one", "dj_store_in_publish_queue",
            "dj_queue_scores", "dj_get_stats", "dj_owner_of", "dj_partition_joins", "dj_profile_enable",
-           "dj_profile_read", "dj_compact", "dj_set_hot_path", "dj_checkpoint_save", "dj_checkpoint_load"]
+           "dj_profile_read", "dj_compact", "dj_set_hot_path", "dj_checkpoint_save", "dj_checkpoint_load",
+           "dj_get_config"]
+# include/dj_batcher.h
+BATCHER_SYMBOLS = ["dj_batcher_create", "dj_batcher_destroy", "dj_batcher_set_clock", "dj_batcher_join",
+                   "dj_batcher_fork", "dj_batcher_join_wait", "dj_batcher_fork_wait", "dj_batcher_run",
+                   "dj_batcher_get_stats"]
+STATUS_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int32)
+CLOCK_CB = ctypes.CFUNCTYPE(ctypes.c_uint64, ctypes.c_void_p)
+TASK_CB = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64)
+
+
+class BatcherConfig(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("max_batch", ctypes.c_uint32), ("max_wait_us", ctypes.c_uint32),
+                ("max_message", ctypes.c_uint32)]
+
+
+class BatcherStats(ctypes.Structure):
+    _fields_ = [("batches", ctypes.c_uint64), ("forks", ctypes.c_uint64), ("joins", ctypes.c_uint64),
+                ("largest_batch", ctypes.c_uint64), ("tasks", ctypes.c_uint64)]
 PROF_KERNELS = ["fork_claim", "fork_apply", "join_link", "join_resolve", "join_complex", "join_copy", "pop", "gather",
                 "ack", "recover", "compact"]
 
@@ -121,6 +139,26 @@ def load():
     L.dj_checkpoint_save.argtypes = [vp, ctypes.c_char_p]
     L.dj_checkpoint_load.restype = i32
     L.dj_checkpoint_load.argtypes = [vp, ctypes.c_char_p]
+    L.dj_get_config.restype = i32
+    L.dj_get_config.argtypes = [vp, vp]
+    L.dj_batcher_create.restype = i32
+    L.dj_batcher_create.argtypes = [vp, ctypes.POINTER(BatcherConfig), ctypes.POINTER(vp)]
+    L.dj_batcher_destroy.restype = None
+    L.dj_batcher_destroy.argtypes = [vp]
+    L.dj_batcher_set_clock.restype = i32
+    L.dj_batcher_set_clock.argtypes = [vp, CLOCK_CB, vp]
+    L.dj_batcher_join.restype = i32
+    L.dj_batcher_join.argtypes = [vp, vp, vp, STATUS_CB, vp]
+    L.dj_batcher_fork.restype = i32
+    L.dj_batcher_fork.argtypes = [vp, vp, STATUS_CB, vp]
+    L.dj_batcher_join_wait.restype = i32
+    L.dj_batcher_join_wait.argtypes = [vp, vp, vp, ctypes.POINTER(ctypes.c_int32)]
+    L.dj_batcher_fork_wait.restype = i32
+    L.dj_batcher_fork_wait.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_int32)]
+    L.dj_batcher_run.restype = i32
+    L.dj_batcher_run.argtypes = [vp, TASK_CB, vp]
+    L.dj_batcher_get_stats.restype = i32
+    L.dj_batcher_get_stats.argtypes = [vp, ctypes.POINTER(BatcherStats)]
     L.dj_compact.restype = i32
     L.dj_compact.argtypes = [vp, ctypes.POINTER(u64)]
     L.dj_profile_enable.restype = i32

@@ -31,10 +31,9 @@ struct dj_engine {
     dj_sweep_result* d_result;   // internal result block when the caller passes none
     uint32_t* d_part_counts;     // partition scratch: blocks * ranks (engine stream)
     uint32_t* d_part_counts2;    // same, for partitions launched on a caller stream
-    void* allocs[64];
+    void* allocs[128];
     int n_allocs;
     std::string err;
-    // optional per-kernel timing (dj_profile_enable): one event pair per kernel id
     Slot* slots_alt;             // second table for dj_compact (always all-empty between calls)
     uint64_t* q_alt;
     int cx_force;                // -1: automatic, 0 / 1: force the serial / parallel hot-barrier kernels (tests)
@@ -48,6 +47,7 @@ struct dj_engine {
     int ctr_bank, sweep_bank;    // which half of the double-banked scratch the next call uses
     unsigned int* d_counters;    // 2 x C_COUNT
     unsigned long long* d_sweep; // 2 x S_COUNT
+    // optional per-kernel timing (dj_profile_enable): one event pair per kernel id
     int profiling;
     hipEvent_t ev_start[DJ_PROF_KERNELS], ev_stop[DJ_PROF_KERNELS];
     int ev_used[DJ_PROF_KERNELS];
@@ -83,7 +83,7 @@ static int fail(dj_engine* e, int code, const char* fmt, ...) {
     } while (0)
 
 static int dev_alloc(dj_engine* e, void** p, size_t bytes) {
-    if (e->n_allocs >= 64) return fail(e, DJ_E_INVALID, "allocation table full");
+    if (e->n_allocs >= 128) return fail(e, DJ_E_INVALID, "allocation table full");
     hipError_t r = hipMalloc(p, bytes ? bytes : 16);
     if (r != hipSuccess) return fail(e, DJ_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(r));
     e->allocs[e->n_allocs++] = *p;
@@ -294,6 +294,12 @@ extern "C" int dj_sync(dj_engine* e) {
 }
 
 extern "C" void* dj_stream(dj_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+extern "C" int dj_get_config(const dj_engine* e, dj_config* out) {
+    if (!e || !out) return DJ_E_INVALID;
+    *out = e->cfg;
+    return DJ_OK;
+}
 
 extern "C" int dj_set_hot_path(dj_engine* e, int mode) {
     if (!e || mode < -1 || mode > 1) return DJ_E_INVALID;

@@ -5,8 +5,8 @@
  * distributed-join.redis (reference src/distributed_join/redis.clj), which is the
  * only way src/distributed_join/core.clj touches barrier state.  One engine owns one
  * GPU: a device-resident open-addressing barrier table in HBM, per-barrier position
- * bitmaps and payload slabs, and the primary / backup publish queues as two
- * per-slot score arrays.  Every call is a batch; per-item results come back in
+ * bitmaps and payload slabs, and the primary / backup publish queues as one queue
+ * word per slot.  Every call is a batch; per-item results come back in
  * caller-provided arrays.
  *
  * Conventions
@@ -142,6 +142,7 @@ void dj_destroy(dj_engine* e);
 const char* dj_last_error(const dj_engine* e);   /* e may be NULL: last create error */
 int  dj_sync(dj_engine* e);                        /* wait for all queued work */
 void* dj_stream(dj_engine* e);                     /* the engine's hipStream_t */
+int  dj_get_config(const dj_engine* e, dj_config* out);   /* the configuration the engine was created with */
 
 /* Fingerprint of a barrier-id (host side, pure function).  Never yields a reserved
  * value.  Replaces the Redis key strings built by make-key (redis.clj:42-47). */

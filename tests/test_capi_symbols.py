@@ -7,10 +7,10 @@ from distributed_join_amd import capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
-    text = open(os.path.join(ROOT, "include", "dj_engine.h")).read()
+def declared_functions(header="dj_engine.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(dj_[a-z_0-9]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(dj_[a-z_0-9]+)\s*\(", text)) - {"dj_status_cb"})
 
 
 def test_header_functions_are_exported_and_bound():
@@ -20,6 +20,14 @@ def test_header_functions_are_exported_and_bound():
     for n in names:
         assert getattr(lib, n) is not None, n
     assert sorted(capi.SYMBOLS) == names
+
+
+def test_batcher_header_functions_are_exported_and_bound():
+    names = declared_functions("dj_batcher.h")
+    lib = capi.load()
+    for n in names:
+        assert getattr(lib, n) is not None, n
+    assert sorted(capi.BATCHER_SYMBOLS) == names
 
 
 def test_record_layouts_match_header_sizes():
