@@ -104,25 +104,6 @@ __global__ void __launch_bounds__(FORK_APPLY_BLOCK) fork_apply_kernel(Table t, W
 // position, the HSET semantics of redis.clj:135).
 // =====================================================================================
 
-// Append one element per thread with pred set, ONE atomic per block (a hot counter word
-// sustains only ~90 atomics per microsecond).  Every thread of the block must call it.
-// lds: 17 words of shared memory.  Returns the index, 0xFFFFFFFF without pred.
-__device__ inline uint32_t block_append(unsigned int* counter, bool pred, uint32_t* lds) {
-    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const uint64_t m = __ballot(pred);
-    if (lane == 0) lds[wv] = (uint32_t)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (uint32_t v = 0; v < nw; ++v) { const uint32_t c = lds[v]; lds[v] = tot; tot += c; }
-        lds[16] = tot ? a_add(counter, tot) : 0u;
-    }
-    __syncthreads();
-    const uint32_t r = lds[16] + lds[wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-    __syncthreads();
-    return pred ? r : 0xFFFFFFFFu;
-}
-
 // HOT = false: independent threads, blocks of 256 (no barrier anywhere: a thread with a long probe
 // sequence delays nobody).  HOT = true (the engine saw a barrier with hundreds of events in the
 // previous batch): blocks of 1024 with block-level pre-aggregation.
