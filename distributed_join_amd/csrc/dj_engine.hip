@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 
@@ -34,6 +35,7 @@ struct dj_engine {
     void* allocs[128];
     int n_allocs;
     std::string err;
+    std::recursive_mutex mu;     // entry points serialise themselves: callers may share an engine between threads
     Slot* slots_alt;             // second table for dj_compact (always all-empty between calls)
     uint64_t* q_alt;
     int cx_force;                // -1: automatic, 0 / 1: force the serial / parallel hot-barrier kernels (tests)
@@ -288,6 +290,7 @@ extern "C" int dj_create(const dj_config* cfg, dj_engine** out) {
 
 extern "C" int dj_sync(dj_engine* e) {
     if (!e) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return DJ_OK;
@@ -303,12 +306,14 @@ extern "C" int dj_get_config(const dj_engine* e, dj_config* out) {
 
 extern "C" int dj_set_hot_path(dj_engine* e, int mode) {
     if (!e || mode < -1 || mode > 1) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
     e->cx_force = mode;
     return DJ_OK;
 }
 
 extern "C" int dj_profile_enable(dj_engine* e, int on) {
     if (!e) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     if (on)
         for (int k = 0; k < DJ_PROF_KERNELS; ++k) {
@@ -322,6 +327,7 @@ extern "C" int dj_profile_enable(dj_engine* e, int on) {
 
 extern "C" int dj_profile_read(dj_engine* e, float* h_ms) {
     if (!e || !h_ms) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     for (int k = 0; k < DJ_PROF_KERNELS; ++k) {
@@ -380,6 +386,7 @@ static int compact_finish(dj_engine* e, bool wait) {
 
 extern "C" int dj_compact(dj_engine* e, uint64_t* h_live) {
     if (!e) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     int rc = compact_finish(e, true);
     if (rc != DJ_OK) return rc;
@@ -394,6 +401,7 @@ extern "C" int dj_compact(dj_engine* e, uint64_t* h_live) {
 // ---- hot path ----------------------------------------------------------------------------
 extern "C" int dj_fork_batch(dj_engine* e, uint32_t n, const dj_fork_rec* d_recs, int32_t* d_status) {
     if (!e) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
     if (n == 0) return DJ_OK;
     if (!d_recs || !d_status || !aligned16(d_recs)) return fail(e, DJ_E_INVALID, "fork: null or misaligned pointer");
     if (n > e->cfg.max_batch) return fail(e, DJ_E_TOO_LARGE, "fork: n=%u exceeds max_batch=%u", n, e->cfg.max_batch);
@@ -433,6 +441,7 @@ static void launch_join_copy(dj_engine* e, uint32_t n, const dj_join_rec* recs, 
 extern "C" int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs, const uint8_t* d_payloads,
                              uint64_t pitch, uint64_t now_ms, int32_t* d_status) {
     if (!e) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
     if (!clock_ok(now_ms)) return fail(e, DJ_E_CLOCK_RANGE, "join: now_ms=%llu outside [1e12, 9e12)", (unsigned long long)now_ms);
     if (n == 0) return DJ_OK;
     if (!d_recs || !d_status || !d_payloads) return fail(e, DJ_E_INVALID, "join: null pointer");
@@ -508,6 +517,7 @@ static int sweep_impl(dj_engine* e, const char* what, uint64_t now_ms, uint32_t 
                       int gather, dj_cont* d_conts, uint32_t* d_lens, uint32_t* d_max_waits, uint8_t* d_payloads,
                       dj_sweep_result* d_result, dj_sweep_result* h_result) {
     if (!e) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
     if (!clock_ok(now_ms)) return fail(e, DJ_E_CLOCK_RANGE, "%s: now_ms=%llu outside [1e12, 9e12)", what, (unsigned long long)now_ms);
     if (!d_conts || cap_conts == 0) return fail(e, DJ_E_INVALID, "%s: no continuation buffer", what);
     if (cap_conts > e->t.mask + 1) cap_conts = (uint32_t)(e->t.mask + 1);
@@ -550,6 +560,7 @@ extern "C" int dj_sweep(dj_engine* e, uint64_t now_ms, uint32_t cap_conts, uint6
 extern "C" int dj_ack_batch(dj_engine* e, uint32_t n, const uint32_t* d_n, const dj_cont* d_conts, const uint8_t* d_ok,
                             uint64_t now_ms, int32_t* d_status) {
     if (!e) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
     if (!clock_ok(now_ms)) return fail(e, DJ_E_CLOCK_RANGE, "ack: now_ms=%llu outside [1e12, 9e12)", (unsigned long long)now_ms);
     if (n == 0) return DJ_OK;
     if (!d_conts || !d_status) return fail(e, DJ_E_INVALID, "ack: null pointer");
@@ -562,6 +573,7 @@ extern "C" int dj_ack_batch(dj_engine* e, uint32_t n, const uint32_t* d_n, const
 extern "C" int dj_recover(dj_engine* e, uint64_t now_ms, uint32_t cap, dj_cont* d_conts, int32_t* d_status,
                           dj_sweep_result* d_result, dj_sweep_result* h_result) {
     if (!e) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
     if (!clock_ok(now_ms)) return fail(e, DJ_E_CLOCK_RANGE, "recover: now_ms=%llu outside [1e12, 9e12)", (unsigned long long)now_ms);
     if (!d_conts || !d_status || cap == 0) return fail(e, DJ_E_INVALID, "recover: no output buffer");
     dj_sweep_result* res = d_result ? d_result : e->d_result;
@@ -581,6 +593,7 @@ extern "C" int dj_recover(dj_engine* e, uint64_t now_ms, uint32_t cap, dj_cont* 
 extern "C" int dj_snapshot_one(dj_engine* e, uint64_t fp_lo, uint64_t fp_hi, int update_ts, dj_cont* h_meta,
                                uint32_t* h_lens, uint32_t* h_max_waits, uint8_t* h_payloads) {
     if (!e || !h_meta) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     lookup_one_kernel<<<1, 64, 0, e->stream>>>(e->t, e->w, fp_lo, fp_hi, e->d_one_cont, e->d_one_scores);
     gather_kernel<64><<<1, 64, 0, e->stream>>>(e->t, e->w, e->d_one_cont, 0, 1, 1, e->cfg.max_count, update_ts ? 1 : 0,
@@ -601,6 +614,7 @@ extern "C" int dj_snapshot_one(dj_engine* e, uint64_t fp_lo, uint64_t fp_hi, int
 
 extern "C" int dj_store_in_publish_queue(dj_engine* e, uint64_t fp_lo, uint64_t fp_hi, uint64_t at_ms) {
     if (!e) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
     if (!clock_ok(at_ms)) return fail(e, DJ_E_CLOCK_RANGE, "store_in_publish_queue: at_ms outside [1e12, 9e12)");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     store_in_queue_one_kernel<<<1, 64, 0, e->stream>>>(e->t, fp_lo, fp_hi, at_ms, e->d_one_err);
@@ -614,6 +628,7 @@ extern "C" int dj_store_in_publish_queue(dj_engine* e, uint64_t fp_lo, uint64_t 
 
 extern "C" int dj_queue_scores(dj_engine* e, uint64_t fp_lo, uint64_t fp_hi, uint64_t* h_primary_at, uint64_t* h_backup_at) {
     if (!e) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     lookup_one_kernel<<<1, 64, 0, e->stream>>>(e->t, e->w, fp_lo, fp_hi, e->d_one_cont, e->d_one_scores);
     HIP_TRY(e, hipGetLastError());
@@ -627,6 +642,7 @@ extern "C" int dj_queue_scores(dj_engine* e, uint64_t fp_lo, uint64_t fp_hi, uin
 
 extern "C" int dj_get_stats(dj_engine* e, dj_stats* h_stats) {
     if (!e || !h_stats) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     unsigned long long st[4], bump;
     unsigned int head[NUM_CLASSES], tail[NUM_CLASSES];
@@ -682,6 +698,7 @@ int file_to_dev(dj_engine* e, FILE* f, void* dev, size_t bytes, void* stage) {
 
 extern "C" int dj_checkpoint_save(dj_engine* e, const char* path) {
     if (!e || !path) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     int rc = compact_finish(e, true);
     if (rc != DJ_OK) return rc;
@@ -723,6 +740,7 @@ extern "C" int dj_checkpoint_save(dj_engine* e, const char* path) {
 
 extern "C" int dj_checkpoint_load(dj_engine* e, const char* path) {
     if (!e || !path) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     int rc = compact_finish(e, true);
     if (rc != DJ_OK) return rc;
@@ -779,6 +797,7 @@ extern "C" int dj_partition_joins(dj_engine* e, uint32_t n, uint32_t n_ranks, co
                                   const uint8_t* d_payloads, uint64_t pitch, dj_join_rec* d_recs_out,
                                   uint8_t* d_payloads_out, uint32_t* d_origin, uint32_t* d_counts, void* stream) {
     if (!e) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
     if (n_ranks < 1 || n_ranks > PART_MAX_RANKS) return fail(e, DJ_E_INVALID, "partition: n_ranks must be 1..%d", PART_MAX_RANKS);
     if (!d_recs || !d_recs_out || !d_origin || !d_counts) return fail(e, DJ_E_INVALID, "partition: null pointer");
     if (!aligned16(d_recs) || !aligned16(d_recs_out)) return fail(e, DJ_E_INVALID, "partition: records must be 16-byte aligned");

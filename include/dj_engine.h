@@ -16,8 +16,9 @@
  *    device); pointers named h_* are host pointers.  The engine never frees or keeps
  *    caller buffers past the call's completion on its stream.
  *  - calls are asynchronous on the engine's HIP stream unless documented
- *    otherwise; dj_sync() waits for them.  Calls on one engine must be serialised
- *    by the caller (one engine = one stream = one mutex on the caller's side).
+ *    otherwise; dj_sync() waits for them.  Calls on one engine serialise themselves
+ *    (one engine = one stream = one internal mutex), so threads may share an engine;
+ *    the ORDER of their batches is then theirs to arrange (include/dj_batcher.h does).
  *  - the engine never reads a clock: now_ms is always an argument.  It must be a
  *    13-digit epoch-milliseconds value (1e12 <= now_ms < 9e12): inside that range
  *    the reference's Lua string comparison of scores (redis.clj:268-269) equals the
