@@ -14,7 +14,7 @@ class Batcher:
         self.e = engine
         self.L = engine.L
         cfg = capi.BatcherConfig(ctypes.sizeof(capi.BatcherConfig), int(max_batch), int(max_wait_us),
-                                 int(max_message if max_message is not None else engine.stride))
+                                 int(max_message if max_message is not None else engine.max_message))
         h = ctypes.c_void_p()
         rc = self.L.dj_batcher_create(engine.h, ctypes.byref(cfg), ctypes.byref(h))
         if rc != 0:

@@ -18,6 +18,7 @@ DJ_NIL = 0xFFFFFFFF
 DJ_NOT_QUEUED = 0xFFFFFFFFFFFFFFFF
 DJ_JOIN_WAITING, DJ_JOIN_COMPLETE, DJ_JOIN_NOT_FOUND = 1, 2, 3
 DJ_JOIN_BAD_POSITION, DJ_JOIN_NEAREST_NOT_QUEUED, DJ_JOIN_TOO_LONG, DJ_JOIN_BAD_MAX_WAIT = 4, 5, 6, 7
+DJ_JOIN_NO_SPACE = 8
 DJ_FORK_CREATED, DJ_FORK_TABLE_FULL, DJ_FORK_NO_SPACE, DJ_FORK_BAD_COUNT = 1, 2, 3, 4
 DJ_ACK_DONE, DJ_ACK_REQUEUED_DIRTY, DJ_ACK_RETRY = 1, 2, 3
 DJ_ACK_DROPPED_EXHAUSTED, DJ_ACK_DONE_NO_METADATA = 4, 5
@@ -32,6 +33,7 @@ JOIN_REC = np.dtype([("fp_lo", "<u8"), ("fp_hi", "<u8"), ("position", "<u4"), ("
 CONT = np.dtype([("fp_lo", "<u8"), ("fp_hi", "<u8"), ("deadline_ms", "<u8"), ("publish_at", "<u8"),
                  ("count", "<u4"), ("flags", "<u4"), ("retry_publish", "<u4"), ("retry_timeout", "<u4"),
                  ("pos_base", "<u8"), ("reserved", "<u8")])
+LONG_REF = np.dtype([("unit", "<u4"), ("size_class", "<u4"), ("len", "<u4"), ("zero", "<u4")])
 SWEEP_RESULT = np.dtype([("n_conts", "<u4"), ("more", "<u4"), ("n_positions", "<u8")])
 STATS = np.dtype([("slots", "<u8"), ("live", "<u8"), ("tombstones", "<u8"), ("arena_units_used", "<u8"),
                   ("arena_units_free", "<u8")])
@@ -44,7 +46,7 @@ class Config(ctypes.Structure):
                 ("capacity_barriers", ctypes.c_uint64), ("arena_bytes", ctypes.c_uint64),
                 ("max_count", ctypes.c_uint32), ("payload_stride", ctypes.c_uint32),
                 ("max_batch", ctypes.c_uint32), ("max_retry_publish", ctypes.c_uint32),
-                ("max_retry_timeout_publish", ctypes.c_uint32), ("reserved0", ctypes.c_uint32),
+                ("max_retry_timeout_publish", ctypes.c_uint32), ("max_message_bytes", ctypes.c_uint32),
                 ("check_publish_delay_ms", ctypes.c_uint64)]
 
 
@@ -54,7 +56,7 @@ SYMBOLS = ["dj_create", "dj_destroy", "dj_last_error", "dj_sync", "dj_stream", "
            "dj_ack_batch", "dj_recover", "dj_snapshot_one", "dj_store_in_publish_queue",
            "dj_queue_scores", "dj_get_stats", "dj_owner_of", "dj_partition_joins", "dj_profile_enable",
            "dj_profile_read", "dj_compact", "dj_set_hot_path", "dj_checkpoint_save", "dj_checkpoint_load",
-           "dj_get_config"]
+           "dj_get_config", "dj_fetch_long"]
 # include/dj_batcher.h
 BATCHER_SYMBOLS = ["dj_batcher_create", "dj_batcher_destroy", "dj_batcher_set_clock", "dj_batcher_join",
                    "dj_batcher_fork", "dj_batcher_join_wait", "dj_batcher_fork_wait", "dj_batcher_run",
@@ -141,6 +143,8 @@ def load():
     L.dj_checkpoint_load.argtypes = [vp, ctypes.c_char_p]
     L.dj_get_config.restype = i32
     L.dj_get_config.argtypes = [vp, vp]
+    L.dj_fetch_long.restype = i32
+    L.dj_fetch_long.argtypes = [vp, u32, vp, vp, vp]
     L.dj_batcher_create.restype = i32
     L.dj_batcher_create.argtypes = [vp, ctypes.POINTER(BatcherConfig), ctypes.POINTER(vp)]
     L.dj_batcher_destroy.restype = None

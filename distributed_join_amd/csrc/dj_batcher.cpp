@@ -170,7 +170,8 @@ extern "C" int dj_batcher_create(dj_engine* e, const dj_batcher_config* cfg, dj_
     if (!e || !cfg || !out || cfg->struct_size != sizeof(dj_batcher_config)) return DJ_E_INVALID;
     dj_config ec;
     if (dj_get_config(e, &ec) != DJ_OK) return DJ_E_INVALID;
-    if (cfg->max_batch < 1 || cfg->max_batch > ec.max_batch || cfg->max_message > ec.payload_stride) return DJ_E_INVALID;
+    const uint32_t longest = ec.max_message_bytes > ec.payload_stride ? ec.max_message_bytes : ec.payload_stride;
+    if (cfg->max_batch < 1 || cfg->max_batch > ec.max_batch || cfg->max_message > longest) return DJ_E_INVALID;
     dj_batcher* b = new (std::nothrow) dj_batcher();
     if (!b) return DJ_E_NOMEM;
     b->e = e;

@@ -36,6 +36,8 @@ constexpr uint64_t Q_NONE = ~0ull;          // in neither queue
 constexpr uint64_t Q_POPPED = 1ull << 63;   // removed from the primary queue, still in the backup queue
 constexpr uint32_t META_HAS = 1u;      // metadata key exists
 constexpr uint32_t META_HOT = 2u;      // hint: the barrier received hundreds of events in its last batch
+constexpr uint32_t META_OVF = 4u;      // some position of the barrier holds (or held) a long message in a block of its own
+constexpr int OVF_CLASSES = 15;        // blocks for long messages: 1 << k units, 64 B .. 1 MiB
 constexpr uint32_t RETRY_NIL = 0xFFu;  // retry counter absent
 constexpr int NUM_CLASSES = 11;        // 1, 2, 4 ... 1024 positions
 constexpr uint64_t NODST = ~0ull;
@@ -96,6 +98,14 @@ struct Table {
     unsigned int* ring_tail;     // [NUM_CLASSES] push side
     unsigned int* ring_tail_snap;// [NUM_CLASSES] tail at the start of the current call: pops stop here
     unsigned long long* stat;    // scratch of stats_kernel: [0] live slots, [1] tombstones
+    // blocks for messages longer than one inline row (only with max_message > stride): the slot row of
+    // such a position starts with a dj_long_ref, its posmeta len is > stride
+    uint32_t* oring[OVF_CLASSES];     // freed blocks per class
+    uint32_t oring_cap[OVF_CLASSES];
+    unsigned int* oring_head;         // [OVF_CLASSES]
+    unsigned int* oring_tail;
+    unsigned int* oring_tail_snap;    // tails before the current join batch's copy pass: pops stop here
+    uint32_t max_message;             // longest message accepted, >= stride
     uint32_t stride;
     uint32_t max_count;
     uint32_t max_retry_publish, max_retry_timeout_publish;
@@ -421,6 +431,78 @@ __device__ inline void block_slab_free(const Table& t, bool has, uint32_t k, uin
     wave_slab_free(t, has && !fast, k, slab);
 }
 
+// ---- blocks for long messages ----------------------------------------------------------------
+__host__ __device__ inline uint32_t ovf_class(uint32_t len) {
+    const uint32_t units = (len + 63) >> 6;
+    uint32_t k = 0;
+    while ((1u << k) < units) ++k;
+    return k;
+}
+
+// Wave-cooperative like the slab helpers.  Returns a block of 1 << k units or 0 (arena exhausted).
+__device__ inline uint32_t wave_ovf_alloc(const Table& t, bool want, uint32_t k) {
+    const uint32_t lane = lane_id();
+    uint32_t unit = 0;
+    uint64_t todo = __ballot(want);
+    while (todo) {
+        const int l0 = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t k0 = __shfl(k, l0);
+        const uint64_t grp = __ballot(want && k == k0);
+        const uint32_t m = (uint32_t)__popcll(grp);
+        const uint32_t rank = (uint32_t)__popcll(grp & ((1ull << lane) - 1));
+        uint32_t h = 0;
+        int got = 0;
+        if ((int)lane == l0) {
+            const unsigned int snap = t.oring_tail_snap[k0];
+            if ((int)(snap - a_load(&t.oring_head[k0])) > 0) {
+                h = a_add(&t.oring_head[k0], m);
+                const int avail = (int)(snap - h);
+                got = avail < 0 ? 0 : (avail > (int)m ? (int)m : avail);
+                if (got < (int)m) a_add(&t.oring_head[k0], (unsigned int)(got - (int)m));
+            }
+        }
+        h = __shfl(h, l0);
+        got = __shfl(got, l0);
+        if (want && k == k0 && (int)rank < got) unit = t.oring[k0][(h + rank) & (t.oring_cap[k0] - 1)];
+        todo &= ~grp;
+    }
+    const bool need = want && unit == 0;
+    const uint32_t units = need ? (1u << k) : 0;
+    const uint32_t incl = wave_incl_scan(units);
+    const uint32_t total = __shfl(incl, 63);
+    if (total == 0) return unit;
+    unsigned long long base = 0;
+    if (lane == 0) base = a_add(t.bump, (unsigned long long)total);
+    base = __shfl(base, 0);
+    uint32_t missed = 0;
+    if (need) {
+        const unsigned long long u = base + incl - units;
+        if (u + units <= t.arena_units) unit = (uint32_t)u;
+        else missed = units;
+    }
+    // what did not fit goes back to the pointer, so that smaller requests can still use the tail
+    const uint32_t back = __shfl(wave_incl_scan(missed), 63);
+    if (back && lane == 0) a_add(t.bump, 0ull - (unsigned long long)back);
+    return unit;
+}
+
+__device__ inline void wave_ovf_free(const Table& t, bool has, uint32_t k, uint32_t unit) {
+    const uint32_t lane = lane_id();
+    has = has && unit != 0 && k < OVF_CLASSES;
+    uint64_t todo = __ballot(has);
+    while (todo) {
+        const int l0 = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t k0 = __shfl(k, l0);
+        const uint64_t grp = __ballot(has && k == k0);
+        const uint32_t rank = (uint32_t)__popcll(grp & ((1ull << lane) - 1));
+        unsigned int tl = 0;
+        if ((int)lane == l0) tl = a_add(&t.oring_tail[k0], (unsigned int)__popcll(grp));
+        tl = __shfl(tl, l0);
+        if (has && k == k0) t.oring[k0][(tl + rank) & (t.oring_cap[k0] - 1)] = unit;
+        todo &= ~grp;
+    }
+}
+
 // redis/complete's deletions (redis.clj:180-185) for a slot this thread owns.  The slab goes
 // back through wave_slab_free by the caller.
 __device__ inline void clear_slot(const Table& t, uint64_t s) {
@@ -446,6 +528,46 @@ __device__ inline uint2* slab_posmeta(const Table& t, uint32_t slab, uint32_t k)
 }
 __device__ inline uint8_t* slab_payload(const Table& t, uint32_t slab, uint32_t k) {
     return t.arena + (uint64_t)slab * 64 + slab_payload_off(k);
+}
+
+// Whole wave, uniform arguments: gives back the long-message blocks of positions [from, to) of one
+// slab (class k) and zeroes their lengths.
+__device__ inline void wave_release_long(const Table& t, uint32_t slab, uint32_t k, uint32_t from, uint32_t to) {
+    uint2* pm = slab_posmeta(t, slab, k);
+    const uint8_t* pay = slab_payload(t, slab, k);
+    for (uint32_t p0 = from; p0 < to; p0 += 64) {
+        const uint32_t p = p0 + lane_id();
+        bool has = false;
+        uint32_t kk = 0, unit = 0;
+        if (p < to) {
+            const uint32_t len = pm[p].x;
+            if (len > t.stride && len != DJ_NIL) {
+                const dj_long_ref ref = *reinterpret_cast<const dj_long_ref*>(pay + (uint64_t)p * t.stride);
+                has = true;
+                kk = ref.size_class;
+                unit = ref.unit;
+                pm[p].x = 0;
+            }
+        }
+        wave_ovf_free(t, has, kk, unit);
+    }
+}
+
+// Every lane of the wave calls this; a lane with `mine` owns a barrier whose blocks must go.
+__device__ inline void wave_release_long_each(const Table& t, bool mine, uint32_t slab, uint32_t k, uint32_t from,
+                                              uint32_t to) {
+    uint64_t todo = __ballot(mine && slab != 0);
+    while (todo) {
+        const int l = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        wave_release_long(t, __shfl(slab, l), __shfl(k, l), __shfl(from, l), __shfl(to, l));
+    }
+}
+
+// A slab that starts a new life (fork): no position holds a long message.
+__device__ inline void zero_posmeta(const Table& t, uint32_t slab, uint32_t k) {
+    uint2* pm = slab_posmeta(t, slab, k);
+    for (uint32_t p = 0; p < class_positions(k); ++p) pm[p] = make_uint2(0, 0);
 }
 
 // node packing of the join link pass: next (25) | position (10) | max-wait (29)

@@ -174,6 +174,7 @@ static int create_impl(dj_engine* e) {
     if (slots > (1ull << 30)) return fail(e, DJ_E_INVALID, "capacity_barriers too large (max 2^29)");
     t.mask = slots - 1;
     t.stride = c.payload_stride;
+    t.max_message = c.max_message_bytes > c.payload_stride ? c.max_message_bytes : c.payload_stride;
     t.max_count = c.max_count;
     t.max_retry_publish = c.max_retry_publish;
     t.max_retry_timeout_publish = c.max_retry_timeout_publish;
@@ -205,6 +206,19 @@ static int create_impl(dj_engine* e) {
         t.ring_cap[k] = (uint32_t)cap;
         ALLOC(e, t.ring[k], cap * 4);
     }
+    // free lists of the long-message blocks: only the classes a message longer than one row can need
+    ALLOC(e, t.oring_head, OVF_CLASSES * 4);
+    ALLOC(e, t.oring_tail, OVF_CLASSES * 4);
+    ALLOC(e, t.oring_tail_snap, OVF_CLASSES * 4);
+    for (uint32_t k = 0; k < OVF_CLASSES; ++k) {
+        const bool used = t.max_message > t.stride && (64ull << k) > t.stride && k <= ovf_class(t.max_message);
+        const uint64_t cap = used ? next_pow2(t.arena_units / (1ull << k) + 1) : 1;
+        t.oring_cap[k] = (uint32_t)cap;
+        ALLOC(e, t.oring[k], cap * 4);
+    }
+    HIP_TRY(e, hipMemsetAsync(t.oring_head, 0, OVF_CLASSES * 4, e->stream));
+    HIP_TRY(e, hipMemsetAsync(t.oring_tail, 0, OVF_CLASSES * 4, e->stream));
+    HIP_TRY(e, hipMemsetAsync(t.oring_tail_snap, 0, OVF_CLASSES * 4, e->stream));
     HIP_TRY(e, hipMemsetAsync(t.slots, 0, slots * sizeof(Slot), e->stream));
     HIP_TRY(e, hipMemsetAsync(t.q, 0xFF, slots * 8, e->stream));
     const unsigned long long one = 1;   // arena unit 0 is reserved: slab 0 means "no slab"
@@ -262,6 +276,7 @@ extern "C" int dj_create(const dj_config* cfg, dj_engine** out) {
     if (cfg->max_count < 1 || cfg->max_count > 999) return fail(nullptr, DJ_E_INVALID, "max_count must be 1..999");
     if (cfg->payload_stride < 64 || cfg->payload_stride % 64 || cfg->payload_stride > (1u << 20))
         return fail(nullptr, DJ_E_INVALID, "payload_stride must be a multiple of 64 in [64, 1 MiB]");
+    if (cfg->max_message_bytes > (1u << 20)) return fail(nullptr, DJ_E_INVALID, "max_message_bytes must be <= 1 MiB");
     if (cfg->max_batch < 1 || cfg->max_batch > (1u << 24)) return fail(nullptr, DJ_E_INVALID, "max_batch must be 1..2^24");
     if (cfg->capacity_barriers < 1) return fail(nullptr, DJ_E_INVALID, "capacity_barriers must be positive");
     if (cfg->max_retry_publish > 200 || cfg->max_retry_timeout_publish > 200)
@@ -435,7 +450,10 @@ static void launch_join_copy(dj_engine* e, uint32_t n, const dj_join_rec* recs, 
     const uint64_t steps = ((uint64_t)n + (64 / G) - 1) / (64 / G);          // wave steps
     uint64_t blocks = (steps + 3) / 4;
     if (blocks > 8192) blocks = 8192;
-    join_copy_kernel<G><<<(uint32_t)blocks, 256, 0, e->stream>>>(e->t, e->w, recs, payloads, pitch, n, status);
+    if (e->t.max_message > e->t.stride)
+        join_copy_long_kernel<G><<<(uint32_t)blocks, 256, 0, e->stream>>>(e->t, e->w, recs, payloads, pitch, n, status);
+    else
+        join_copy_kernel<G><<<(uint32_t)blocks, 256, 0, e->stream>>>(e->t, e->w, recs, payloads, pitch, n, status);
 }
 
 extern "C" int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs, const uint8_t* d_payloads,
@@ -557,6 +575,20 @@ extern "C" int dj_sweep(dj_engine* e, uint64_t now_ms, uint32_t cap_conts, uint6
                       d_result, h_result);
 }
 
+extern "C" int dj_fetch_long(dj_engine* e, uint32_t n, const dj_long_ref* d_refs, const uint64_t* d_offsets, uint8_t* d_out) {
+    if (!e) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
+    if (n == 0) return DJ_OK;
+    if (!d_refs || !d_offsets || !d_out || !aligned16(d_refs) || !aligned16(d_out))
+        return fail(e, DJ_E_INVALID, "fetch_long: null or misaligned pointer");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    uint64_t blocks = ((uint64_t)n + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    fetch_long_kernel<<<(uint32_t)blocks, 256, 0, e->stream>>>(e->t, n, d_refs, d_offsets, d_out);
+    HIP_TRY(e, hipGetLastError());
+    return DJ_OK;
+}
+
 extern "C" int dj_ack_batch(dj_engine* e, uint32_t n, const uint32_t* d_n, const dj_cont* d_conts, const uint8_t* d_ok,
                             uint64_t now_ms, int32_t* d_status) {
     if (!e) return DJ_E_INVALID;
@@ -657,10 +689,14 @@ extern "C" int dj_get_stats(dj_engine* e, dj_stats* h_stats) {
     h_stats->slots = e->t.mask + 1;
     h_stats->live = st[0];
     h_stats->tombstones = st[1];
-    h_stats->arena_units_used = bump;
+    h_stats->arena_units_used = bump < e->t.arena_units ? bump : e->t.arena_units;   // refused slab requests leave it past the end
     h_stats->arena_units_free = 0;
     for (uint32_t k = 0; k < NUM_CLASSES; ++k)
         h_stats->arena_units_free += (uint64_t)(tail[k] - head[k]) * slab_units(k, e->t.stride);
+    unsigned int ohead[OVF_CLASSES], otail[OVF_CLASSES];
+    HIP_TRY(e, hipMemcpy(ohead, e->t.oring_head, sizeof ohead, hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(otail, e->t.oring_tail, sizeof otail, hipMemcpyDeviceToHost));
+    for (uint32_t k = 0; k < OVF_CLASSES; ++k) h_stats->arena_units_free += (uint64_t)(otail[k] - ohead[k]) << k;
     return DJ_OK;
 }
 
@@ -671,6 +707,8 @@ struct CkptHeader {
     uint64_t slots, arena_units_used, arena_units_total;
     uint32_t stride, max_count;
     uint32_t ring_n[NUM_CLASSES];    // free slabs per class, stored head-first after the arena
+    uint32_t oring_n[OVF_CLASSES];   // free long-message blocks per class, after the slab lists
+    uint32_t max_message;
     uint64_t used_upper;
 };
 const size_t CKPT_CHUNK = 64u << 20;
@@ -705,11 +743,12 @@ extern "C" int dj_checkpoint_save(dj_engine* e, const char* path) {
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     CkptHeader h;
     memset(&h, 0, sizeof h);
-    memcpy(h.magic, "DJCKPT1", 8);
+    memcpy(h.magic, "DJCKPT2", 8);
     h.slots = e->t.mask + 1;
     h.arena_units_total = e->t.arena_units;
     h.stride = e->t.stride;
     h.max_count = e->t.max_count;
+    h.max_message = e->t.max_message;
     h.used_upper = e->used_upper;
     unsigned long long bump;
     unsigned int head[NUM_CLASSES], tail[NUM_CLASSES];
@@ -718,6 +757,10 @@ extern "C" int dj_checkpoint_save(dj_engine* e, const char* path) {
     HIP_TRY(e, hipMemcpy(tail, e->t.ring_tail, sizeof tail, hipMemcpyDeviceToHost));
     h.arena_units_used = bump < e->t.arena_units ? bump : e->t.arena_units;
     for (uint32_t k = 0; k < NUM_CLASSES; ++k) h.ring_n[k] = tail[k] - head[k];
+    unsigned int ohead[OVF_CLASSES], otail[OVF_CLASSES];
+    HIP_TRY(e, hipMemcpy(ohead, e->t.oring_head, sizeof ohead, hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(otail, e->t.oring_tail, sizeof otail, hipMemcpyDeviceToHost));
+    for (uint32_t k = 0; k < OVF_CLASSES; ++k) h.oring_n[k] = otail[k] - ohead[k];
     FILE* f = fopen(path, "wb");
     if (!f) return fail(e, DJ_E_INVALID, "checkpoint: cannot open %s for writing", path);
     void* stage = malloc(CKPT_CHUNK);
@@ -732,6 +775,12 @@ extern "C" int dj_checkpoint_save(dj_engine* e, const char* path) {
         const uint32_t first = n < cap - at ? n : cap - at;
         rc = dev_to_file(e, f, e->t.ring[k] + at, (size_t)first * 4, stage);
         if (rc == DJ_OK) rc = dev_to_file(e, f, e->t.ring[k], (size_t)(n - first) * 4, stage);
+    }
+    for (uint32_t k = 0; k < OVF_CLASSES && rc == DJ_OK; ++k) {
+        const uint32_t cap = e->t.oring_cap[k], n = h.oring_n[k], at = ohead[k] & (cap - 1);
+        const uint32_t first = n < cap - at ? n : cap - at;
+        rc = dev_to_file(e, f, e->t.oring[k] + at, (size_t)first * 4, stage);
+        if (rc == DJ_OK) rc = dev_to_file(e, f, e->t.oring[k], (size_t)(n - first) * 4, stage);
     }
     free(stage);
     if (fclose(f) != 0 && rc == DJ_OK) rc = fail(e, DJ_E_INVALID, "checkpoint: close failed");
@@ -748,12 +797,12 @@ extern "C" int dj_checkpoint_load(dj_engine* e, const char* path) {
     FILE* f = fopen(path, "rb");
     if (!f) return fail(e, DJ_E_INVALID, "checkpoint: cannot open %s", path);
     CkptHeader h;
-    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "DJCKPT1", 8) != 0) {
+    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "DJCKPT2", 8) != 0) {
         fclose(f);
         return fail(e, DJ_E_INVALID, "checkpoint: %s is not a checkpoint file", path);
     }
     if (h.slots != e->t.mask + 1 || h.stride != e->t.stride || h.max_count != e->t.max_count ||
-        h.arena_units_used > e->t.arena_units) {
+        h.max_message != e->t.max_message || h.arena_units_used > e->t.arena_units) {
         fclose(f);
         return fail(e, DJ_E_INVALID, "checkpoint: saved with slots=%llu stride=%u max_count=%u arena_used=%llu units, "
                     "engine has slots=%llu stride=%u max_count=%u arena=%llu units",
@@ -764,6 +813,11 @@ extern "C" int dj_checkpoint_load(dj_engine* e, const char* path) {
         if (h.ring_n[k] > e->t.ring_cap[k]) {
             fclose(f);
             return fail(e, DJ_E_INVALID, "checkpoint: free list of class %u does not fit", k);
+        }
+    for (uint32_t k = 0; k < OVF_CLASSES; ++k)
+        if (h.oring_n[k] > e->t.oring_cap[k]) {
+            fclose(f);
+            return fail(e, DJ_E_INVALID, "checkpoint: block free list of class %u does not fit", k);
         }
     void* stage = malloc(CKPT_CHUNK);
     if (!stage) { fclose(f); return fail(e, DJ_E_NOMEM, "checkpoint: no staging memory"); }
@@ -776,6 +830,12 @@ extern "C" int dj_checkpoint_load(dj_engine* e, const char* path) {
         head[k] = 0;
         tail[k] = h.ring_n[k];
     }
+    unsigned int ohead[OVF_CLASSES], otail[OVF_CLASSES];
+    for (uint32_t k = 0; k < OVF_CLASSES && rc == DJ_OK; ++k) {
+        rc = file_to_dev(e, f, e->t.oring[k], (size_t)h.oring_n[k] * 4, stage);
+        ohead[k] = 0;
+        otail[k] = h.oring_n[k];
+    }
     free(stage);
     fclose(f);
     if (rc != DJ_OK) return rc;      // the engine's state is undefined after a failed load of a valid header
@@ -784,6 +844,9 @@ extern "C" int dj_checkpoint_load(dj_engine* e, const char* path) {
     HIP_TRY(e, hipMemcpy(e->t.ring_head, head, sizeof head, hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(e->t.ring_tail, tail, sizeof tail, hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(e->t.ring_tail_snap, tail, sizeof tail, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->t.oring_head, ohead, sizeof ohead, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->t.oring_tail, otail, sizeof otail, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->t.oring_tail_snap, otail, sizeof otail, hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemset(e->d_counters, 0, 2 * C_COUNT * 4));
     HIP_TRY(e, hipMemset(e->d_sweep, 0, 2 * S_COUNT * 8));
     e->used_upper = h.used_upper;

@@ -47,8 +47,9 @@ __global__ void __launch_bounds__(FORK_APPLY_BLOCK) fork_apply_kernel(Table t, W
     __shared__ uint32_t lds[24];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     // phase A (per lane): is this record the winner of its slot, and does the slot need a new slab
-    bool active = false, need = false;
-    uint32_t s = 0xFFFFFFFFu, k_new = 0, k_old = 0, old_slab = 0;
+    bool active = false, need = false, had_long = false;
+    uint32_t s = 0xFFFFFFFFu, k_new = 0, k_old = 0, old_slab = 0, old_count = 0;
+    const bool long_on = t.max_message > t.stride;
     dj_fork_rec r = {};
     Slot* sl = nullptr;
     if (i < n) s = w.slot_of[i];
@@ -60,11 +61,15 @@ __global__ void __launch_bounds__(FORK_APPLY_BLOCK) fork_apply_kernel(Table t, W
         r = recs[i];
         k_new = class_of(r.count);
         old_slab = sl->slab;
-        k_old = class_of(sl->count);
+        old_count = sl->count;
+        k_old = class_of(old_count);
         need = old_slab == 0 || k_old != k_new;
+        had_long = long_on && (sl->meta & META_OVF) != 0;
     }
     // phase B (block-cooperative): one ring pop + one bump add per block
     const uint32_t fresh = block_slab_alloc(t, need, k_new, lds);
+    // a barrier that is reset gives its long-message blocks back (not when the reset is refused below)
+    if (long_on) wave_release_long_each(t, had_long && !(need && fresh == 0), old_slab, k_old, 0, old_count);
     wave_slab_free(t, need && fresh != 0, k_old, old_slab);
     if (!active) return;
     // phase C (per lane)
@@ -83,6 +88,7 @@ __global__ void __launch_bounds__(FORK_APPLY_BLOCK) fork_apply_kernel(Table t, W
         uint64_t* bm = slab_bitmap(t, slab);
         for (uint32_t j = 0; j < (class_positions(k_new) >> 6); ++j) bm[j] = 0;
     }
+    if (long_on) zero_posmeta(t, slab, k_new);             // no position holds a long message
     sl->count = r.count;                                  // SET <id>:metadata
     sl->meta = meta_pack(true, RETRY_NIL, RETRY_NIL);
     sl->slab = slab;
@@ -134,7 +140,7 @@ join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t 
         int32_t st = 0;
         int64_t s = -1;
         uint4 info = make_uint4(0, 0, 0, 0);               // count, meta, slab, chain of the slot
-        if (b.y > t.stride || b.y > pitch) {
+        if (b.y > t.max_message || b.y > pitch) {
             st = DJ_JOIN_TOO_LONG;                         // store.clj:24-26
         } else if (b.z >= NODE_MW_LIMIT) {
             st = DJ_JOIN_BAD_MAX_WAIT;                     // engine limit (store.clj:27 caps it far lower)
@@ -224,6 +230,8 @@ constexpr int CHAIN_REG = 8;   // chains up to this length are replayed from reg
 
 __global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint32_t n, uint64_t now, int32_t* status) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    // block pops of the copy pass stop at the tails as they are now (nothing touches these rings here)
+    if (blockIdx.x == 0 && threadIdx.x < OVF_CLASSES) t.oring_tail_snap[threadIdx.x] = t.oring_tail[threadIdx.x];
     bool is_complex = false;
     uint32_t s = tid < n ? w.ev_slot[tid] : 0xFFFFFFFFu;
     // The event that linked FIRST (it found the chain empty) resolves the barrier: it knows that from
@@ -538,6 +546,126 @@ __global__ void __launch_bounds__(256) join_copy_kernel(Table t, Work w, const d
     }
 }
 
+// The same pass for engines that accept messages longer than one inline row (max_message > stride).
+// A long message gets a block of its own from the arena (wave-cooperative alloc / free, a block of
+// the same size class is reused when a position is overwritten); the row keeps a dj_long_ref and
+// posmeta the true length.  Long messages are copied by the whole wave, one after the other.
+template <int G>
+__global__ void __launch_bounds__(256) join_copy_long_kernel(Table t, Work w, const dj_join_rec* recs,
+                                                             const uint8_t* payloads, uint64_t pitch, uint32_t n,
+                                                             int32_t* status) {
+    constexpr int EPW = 64 / G;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t sub = lane / G, j0 = lane % G;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    if (blockIdx.x == 0 && threadIdx.x < C_COUNT) w.counters_next[threadIdx.x] = 0;
+    const bool hot = w.cx_on && w.counters[C_COMPLEX] != 0;
+    for (uint64_t base = wave * EPW; base < n; base += waves * EPW) {      // uniform across the wave
+        const uint64_t i = base + sub;
+        bool live = i < n;
+        uint64_t d = NODST;
+        uint4 b = make_uint4(0, 0, 0, 0);
+        if (live) {
+            d = w.dst[i];
+            live = d != NODST;
+        }
+        const uint32_t slab = (uint32_t)d, k = live ? class_of((uint32_t)(d >> 32)) : 0;
+        if (live) {
+            b = reinterpret_cast<const uint4*>(recs)[2 * i + 1];   // position, len, max_wait
+            if (hot) {
+                const uint32_t c = cx_lookup(w, slab);
+                if (c != IDX_NONE) {
+                    const uint32_t T = w.cx_T[c];
+                    if (j0 == 0) {
+                        if (T != IDX_NONE && i >= T) status[i] = DJ_JOIN_COMPLETE;
+                        else if (b.z && w.cx_nq[c]) status[i] = DJ_JOIN_NEAREST_NOT_QUEUED;
+                    }
+                    if (w.cx_fmax[c * 1024 + b.x] != (uint32_t)i + 1) live = false;
+                }
+            }
+        }
+        // the first lane of each event decides what happens to the position's block
+        const bool lead = live && j0 == 0;
+        const bool new_long = live && b.y > t.stride;
+        bool want = false, give_back = false;
+        uint32_t k_new = 0, k_old = 0, unit_old = 0, unit_new = 0;
+        uint8_t* row = nullptr;
+        if (lead) {
+            row = slab_payload(t, slab, k) + (uint64_t)b.x * t.stride;
+            const uint32_t old_len = slab_posmeta(t, slab, k)[b.x].x;
+            const bool old_long = old_len > t.stride && old_len != DJ_NIL;
+            if (old_long) {
+                const dj_long_ref ref = *reinterpret_cast<const dj_long_ref*>(row);
+                unit_old = ref.unit;
+                k_old = ref.size_class;
+            }
+            if (new_long) {
+                k_new = ovf_class(b.y);
+                if (old_long && k_old == k_new) unit_new = unit_old;      // same size class: write in place
+                else { want = true; give_back = old_long; }
+            } else {
+                give_back = old_long;
+            }
+        }
+        wave_ovf_free(t, give_back, k_old, unit_old);
+        const uint32_t fresh = wave_ovf_alloc(t, want, k_new);
+        if (lead) {
+            if (want) unit_new = fresh;
+            uint32_t len = b.y;
+            if (new_long && unit_new == 0) {                  // arena exhausted: the position keeps an empty message
+                status[i] = DJ_JOIN_NO_SPACE;
+                len = 0;
+            }
+            slab_posmeta(t, slab, k)[b.x] = make_uint2(len, b.z);
+            if (new_long && unit_new != 0) {
+                dj_long_ref ref;
+                ref.unit = unit_new; ref.size_class = k_new; ref.len = b.y; ref.zero = 0;
+                *reinterpret_cast<dj_long_ref*>(row) = ref;
+                atomicOr(&t.slots[w.ev_slot[i]].meta, META_OVF);
+            }
+        }
+        if (live && !new_long) {
+            const uint4* src = reinterpret_cast<const uint4*>(payloads + i * pitch);
+            uint4* dstp = reinterpret_cast<uint4*>(slab_payload(t, slab, k) + (uint64_t)b.x * t.stride);
+            const uint32_t chunks = (b.y + 15) >> 4;
+            for (uint32_t c = j0; c < chunks; c += G) nt_store(&dstp[c], nt_load(&src[c]));
+        }
+        // long messages: the whole wave copies one after the other
+        uint64_t todo = __ballot(lead && new_long && unit_new != 0);
+        while (todo) {
+            const int l = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const uint32_t ev_lo = __shfl((uint32_t)i, l), ev_hi = __shfl((uint32_t)(i >> 32), l);
+            const uint64_t ev = ((uint64_t)ev_hi << 32) | ev_lo;
+            const uint32_t unit = __shfl(unit_new, l), len = __shfl(b.y, l);
+            const uint4* src = reinterpret_cast<const uint4*>(payloads + ev * pitch);
+            uint4* dstp = reinterpret_cast<uint4*>(t.arena + (uint64_t)unit * 64);
+            const uint32_t chunks = (len + 15) >> 4;
+            for (uint32_t c = lane; c < chunks; c += 64) nt_store(&dstp[c], nt_load(&src[c]));
+        }
+    }
+}
+
+// Copies long messages out of the arena (dj_fetch_long): one wave per reference.
+__global__ void __launch_bounds__(256) fetch_long_kernel(Table t, uint32_t n, const dj_long_ref* refs,
+                                                         const uint64_t* offsets, uint8_t* out) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
+    const uint64_t waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t i = wave; i < n; i += waves) {
+        const dj_long_ref r = refs[i];
+        const uint64_t block_bytes = 64ull << (r.size_class < OVF_CLASSES ? r.size_class : 0);
+        if (r.size_class >= OVF_CLASSES || r.unit == 0 || r.len > block_bytes ||
+            (uint64_t)r.unit + (block_bytes >> 6) > t.arena_units || (offsets[i] & 15))
+            continue;                                          // not a reference into this arena
+        const uint4* src = reinterpret_cast<const uint4*>(t.arena + (uint64_t)r.unit * 64);
+        uint4* dstp = reinterpret_cast<uint4*>(out + offsets[i]);
+        const uint32_t chunks = (r.len + 15) >> 4;
+        for (uint32_t c = lane; c < chunks; c += 64) dstp[c] = src[c];
+    }
+}
+
 // =====================================================================================
 // sweep: redis/all-publish-messages (redis.clj:283-289) then, per popped barrier,
 // join-metadata, timeout classification (core.clj:86-95) and redis/all-joins (redis.clj:210-243)
@@ -707,7 +835,9 @@ __global__ void __launch_bounds__(256) gather_kernel(Table t, Work w, const dj_c
         for (uint32_t it = j; it < items; it += GS) {
             const uint32_t p = it / CH, ch = it - p * CH;
             const bool present = count > 64 ? ((bm[p >> 6] >> (p & 63)) & 1) : ((bits0 >> p) & 1);
-            if (!present || ch >= ((pm[p].x + 15) >> 4)) continue;
+            if (!present) continue;
+            const uint32_t len = pm[p].x;       // a long message leaves its 16-byte reference in the row
+            if (ch >= (len > t.stride ? 1u : ((len + 15) >> 4))) continue;
             nt_store(&reinterpret_cast<uint4*>(payloads + (pos_base + p) * (uint64_t)t.stride)[ch],
                      nt_load(&reinterpret_cast<const uint4*>(pay + (uint64_t)p * t.stride)[ch]));
         }
@@ -727,7 +857,7 @@ __device__ inline bool complete_decide(const Table& t, uint64_t s, uint64_t now)
     Slot* sl = &t.slots[s];
     if (sl->join_ts == sl->join_ts_read) return true;          // two nils compare equal
     // reset-publish: both retry counters dropped, :publish-retry-cnt 0, re-queued at now
-    sl->meta = meta_pack(sl->meta & META_HAS, 0, RETRY_NIL);
+    sl->meta = meta_pack(sl->meta & META_HAS, 0, RETRY_NIL) | (sl->meta & META_OVF);
     t.q[s] = now;
     return false;
 }
@@ -745,7 +875,7 @@ __device__ inline bool retries_left(const Table& t, uint64_t deadline, uint32_t 
 __device__ inline void retry_requeue(const Table& t, uint64_t s, bool timeout, uint32_t cnt, uint32_t rp, uint32_t rt,
                                      uint64_t now) {
     if (timeout) rt = cnt + 1; else rp = cnt + 1;
-    t.slots[s].meta = meta_pack(true, rp, rt);
+    t.slots[s].meta = meta_pack(true, rp, rt) | (t.slots[s].meta & META_OVF);
     t.q[s] = now;
 }
 
@@ -762,6 +892,10 @@ __global__ void __launch_bounds__(ACK_BLOCK) ack_kernel(Table t, uint32_t n_max,
     bool clear = false, free_old = false, alloc = false, write_back = false, timeout = false;
     uint64_t s_u = 0;
     uint32_t k_old = 0, old_slab = 0, k_new = 0, cnt = 0, rp = RETRY_NIL, rt = RETRY_NIL;
+    // long-message blocks to give back: positions [rel_from, rel_to) of slab rel_slab (class rel_k)
+    const bool long_on = t.max_message > t.stride;
+    bool rel = false;
+    uint32_t rel_slab = 0, rel_k = 0, rel_from = 0, rel_to = 0;
     dj_cont c = {};
     const bool live = i < n;
     if (live) c = conts[i];
@@ -792,6 +926,9 @@ __global__ void __launch_bounds__(ACK_BLOCK) ack_kernel(Table t, uint32_t n_max,
                 old_slab = t.slots[s].slab;
                 k_old = class_of(t.slots[s].count);
                 free_old = old_slab != 0;
+                if (long_on && (t.slots[s].meta & META_OVF)) {
+                    rel = true; rel_slab = old_slab; rel_k = k_old; rel_from = 0; rel_to = t.slots[s].count;
+                }
             } else {
                 st = DJ_ACK_REQUEUED_DIRTY;
             }
@@ -818,14 +955,21 @@ __global__ void __launch_bounds__(ACK_BLOCK) ack_kernel(Table t, uint32_t n_max,
                         k_old = class_of(sl->count);
                         free_old = old_slab != 0;
                         alloc = true;
-                    } else if (c.count <= 64) {
-                        sl->bits &= c.count == 64 ? ~0ull : ((1ull << c.count) - 1);
+                        if (long_on && (sl->meta & META_OVF)) {
+                            rel = true; rel_slab = old_slab; rel_k = k_old; rel_from = 0; rel_to = sl->count;
+                        }
+                    } else {
+                        if (c.count <= 64) sl->bits &= c.count == 64 ? ~0ull : ((1ull << c.count) - 1);
+                        if (long_on && (sl->meta & META_OVF) && c.count < sl->count) {
+                            rel = true; rel_slab = sl->slab; rel_k = k_new; rel_from = c.count; rel_to = sl->count;
+                        }
                     }
                 }
             }
         }
     }
     // ---- phase B (block- and wave-cooperative): slab traffic, one atomic per size class ---------
+    if (long_on) wave_release_long_each(t, rel, rel_slab, rel_k, rel_from, rel_to);
     block_slab_free(t, free_old, k_old, old_slab, lds);
     const uint32_t fresh = wave_slab_alloc(t, alloc, k_new);
     // ---- phase C (per lane): finish ------------------------------------------------------------------
@@ -835,6 +979,7 @@ __global__ void __launch_bounds__(ACK_BLOCK) ack_kernel(Table t, uint32_t n_max,
         if (alloc) {
             sl->slab = fresh;
             sl->bits = 0;
+            if (long_on && fresh) zero_posmeta(t, fresh, k_new);
             if (c.count > 64 && fresh) {
                 uint64_t* bm = slab_bitmap(t, fresh);
                 for (uint32_t j = 0; j < (class_positions(k_new) >> 6); ++j) bm[j] = 0;
@@ -890,6 +1035,8 @@ __global__ void __launch_bounds__(256) recover_kernel(Table t, uint64_t now, uin
                 st = DJ_ACK_REQUEUED_DIRTY;
             }
         }
+        if (t.max_message > t.stride)
+            wave_release_long_each(t, clear && (sl.meta & META_OVF) != 0, old_slab, k_old, 0, sl.count);
         wave_slab_free(t, clear && old_slab != 0, k_old, old_slab);
         if (clear) clear_slot(t, s);
         if (due) {

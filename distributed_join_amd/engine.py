@@ -43,18 +43,19 @@ def from_device(t, dtype, count=None):
 class Engine:
     def __init__(self, capacity_barriers, arena_bytes, max_count=999, payload_stride=64, max_batch=1 << 20,
                  check_publish_delay_ms=10000, max_retry_publish=3, max_retry_timeout_publish=3, device=0,
-                 host_cap_conts=1 << 16, host_cap_positions=1 << 20):
+                 host_cap_conts=1 << 16, host_cap_positions=1 << 20, max_message_bytes=0):
         torch = _torch()
         if not torch.cuda.is_available():
             raise EngineError("no GPU visible: the barrier engine has no CPU implementation")
         self.L = capi.load()
         self.device = torch.device("cuda", device)
         self.stride = int(payload_stride)
+        self.max_message = max(int(max_message_bytes), self.stride)     # messages above stride live in blocks of their own
         self.max_count = int(max_count)
         self.max_batch = int(max_batch)
         cfg = capi.Config(ctypes.sizeof(capi.Config), device, int(capacity_barriers), int(arena_bytes),
                           int(max_count), int(payload_stride), int(max_batch), int(max_retry_publish),
-                          int(max_retry_timeout_publish), 0, int(check_publish_delay_ms))
+                          int(max_retry_timeout_publish), int(max_message_bytes), int(check_publish_delay_ms))
         h = ctypes.c_void_p()
         torch.cuda.init()
         with torch.cuda.device(self.device):
@@ -182,7 +183,42 @@ class Engine:
         mws = from_device(b["mws"][: max(npos, 1) * 4], np.uint32, npos)
         pay = (from_device(b["pay"][: max(npos, 1) * self.stride], np.uint8, npos * self.stride).reshape(npos, self.stride)
                if with_payloads else np.zeros((npos, self.stride), np.uint8))
+        if with_payloads and self.max_message > self.stride:
+            valid = np.zeros(npos, dtype=bool)          # positions of continuations that were gathered
+            for c in conts:
+                if not int(c["flags"]) & (capi.CONT_VOID | capi.DJ_CONT_NO_METADATA):
+                    valid[int(c["pos_base"]):int(c["pos_base"]) + int(c["count"])] = True
+            pay = self.resolve_long(np.where(valid, lens, capi.DJ_NIL), pay)
         return conts, lens, mws, pay, bool(res[0]["more"])
+
+    def fetch_long_dev(self, n, d_refs, d_offsets, d_out):
+        self._check(self.L.dj_fetch_long(self.h, int(n), d_refs.data_ptr(), d_offsets.data_ptr(), d_out.data_ptr()))
+
+    def resolve_long(self, lens, rows):
+        """Host-layer convenience: rows (n, stride) as a sweep / snapshot returned them; positions whose
+        length exceeds the stride hold a dj_long_ref.  Returns rows wide enough for the longest message
+        with the long messages fetched (dj_fetch_long).  Call before anything else changes the barriers."""
+        lens = np.asarray(lens)
+        if self.max_message <= self.stride:
+            return rows
+        idx = np.nonzero((lens != capi.DJ_NIL) & (lens > self.stride))[0]
+        if len(idx) == 0:
+            return rows
+        width = (int(lens[idx].max()) + 15) // 16 * 16
+        out = np.zeros((len(lens), max(width, self.stride)), dtype=np.uint8)
+        out[:, :self.stride] = rows
+        refs = np.ascontiguousarray(rows[idx, :16]).view(capi.LONG_REF).reshape(-1)
+        assert (refs["len"] == lens[idx]).all(), "row reference and length disagree"
+        sizes = (lens[idx].astype(np.int64) + 15) // 16 * 16
+        offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
+        d_out = self.empty(int(sizes.sum()))
+        self.fetch_long_dev(len(idx), to_device(refs, self.device), to_device(offs, self.device), d_out)
+        self.sync()
+        flat = d_out.cpu().numpy()
+        for j, p in enumerate(idx):
+            ln = int(lens[p])
+            out[p, :ln] = flat[int(offs[j]):int(offs[j]) + ln]
+        return out
 
     def pop_due(self, now_ms):
         b = self._bufs()
@@ -222,7 +258,7 @@ class Engine:
                                            meta.ctypes.data_as(vp), lens.ctypes.data_as(vp), mws.ctypes.data_as(vp),
                                            pay.ctypes.data_as(vp)))
         c = int(meta[0]["count"])
-        return meta[0], lens[:c], mws[:c], pay[:c]
+        return meta[0], lens[:c], mws[:c], self.resolve_long(lens[:c], pay[:c])
 
     def store_in_publish_queue(self, fp_lo, fp_hi, at_ms):
         self._check(self.L.dj_store_in_publish_queue(self.h, int(fp_lo), int(fp_hi), int(at_ms)))

@@ -152,7 +152,7 @@ class EngineStore:
         n = len(ids)
         recs = np.zeros(n, dtype=capi.JOIN_REC)
         longest = max([len(m) for m in messages] + [1])
-        pitch = (min(longest, self.e.stride) + 15) // 16 * 16
+        pitch = (min(longest, self.e.max_message) + 15) // 16 * 16
         pay = np.zeros((n, pitch), dtype=np.uint8)
         for k in range(n):
             recs[k]["fp_lo"], recs[k]["fp_hi"] = self._fp(ids[k])

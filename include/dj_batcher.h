@@ -36,7 +36,7 @@ typedef struct dj_batcher_config {
     uint32_t struct_size;       /* sizeof(dj_batcher_config) */
     uint32_t max_batch;         /* requests per kind and batch, 1..dj_config.max_batch of the engine */
     uint32_t max_wait_us;       /* a batch is closed at the latest this long after its first request */
-    uint32_t max_message;       /* longest message in bytes the staging buffers hold (<= payload_stride) */
+    uint32_t max_message;       /* longest message in bytes the staging buffers hold (<= the engine's limit) */
 } dj_batcher_config;
 
 typedef struct dj_batcher_stats {

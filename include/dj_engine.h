@@ -63,6 +63,8 @@ typedef struct dj_engine dj_engine;
                                           the position was already stored                           */
 #define DJ_JOIN_TOO_LONG            6  /* 400: message longer than dj_config.payload_stride
                                           (store.clj:24-26 with the engine's own limit)             */
+#define DJ_JOIN_NO_SPACE            8  /* engine limit: the arena has no room for this long message; the position
+                                          is stored with an empty message                           */
 #define DJ_JOIN_BAD_MAX_WAIT        7  /* 400: max_wait_s >= 2^29 (store.clj:27-28 with the engine's own
                                           limit; the reference's configured limits are 500..6000 s)  */
 /* dj_fork_batch: core/fork (core.clj:24-33) */
@@ -85,11 +87,14 @@ typedef struct dj_config {
     uint64_t capacity_barriers;         /* max live barriers; table slots = next pow2 >= 2x */
     uint64_t arena_bytes;               /* payload arena size in bytes */
     uint32_t max_count;                 /* :fork-count-max, <= 999 (config.edn:33) */
-    uint32_t payload_stride;            /* bytes reserved per position; multiple of 64; max message bytes */
+    uint32_t payload_stride;            /* bytes reserved per position (inline row); multiple of 64 */
     uint32_t max_batch;                 /* largest n accepted by one batch call, <= 2^24 */
     uint32_t max_retry_publish;         /* :max-retry-post-publish          (config.edn:24) */
     uint32_t max_retry_timeout_publish; /* :max-retry-post-timeout-publish  (config.edn:25) */
-    uint32_t reserved0;
+    uint32_t max_message_bytes;         /* longest message accepted (:join-message-len-max, config.edn:38), up to
+                                           1 MiB; 0 or <= payload_stride: messages are limited to payload_stride.
+                                           Messages longer than payload_stride live in blocks of their own
+                                           (dj_long_ref below) */
     uint64_t check_publish_delay_ms;    /* :check-publish-delay-ms          (config.edn:16) */
 } dj_config;
 
@@ -129,6 +134,18 @@ typedef struct dj_cont {
                                    its message bytes start at d_payloads + pos_base * payload_stride */
     uint64_t reserved;
 } dj_cont;
+
+/* A message longer than payload_stride is not copied into the sweep's / snapshot's payload rows:
+ * its row starts with this 16-byte reference instead (d_lens[...] still holds the true length, which
+ * is how a reader tells: len > payload_stride).  dj_fetch_long copies the bytes out.  A reference
+ * stays valid until the next call that can change the barrier (join of that position, ack, fork of
+ * the same id, recover); fetch right after the sweep. */
+typedef struct dj_long_ref {
+    uint32_t unit;              /* arena offset in 64-byte units */
+    uint32_t size_class;        /* the block holds 64 << size_class bytes */
+    uint32_t len;               /* message length in bytes */
+    uint32_t zero;
+} dj_long_ref;
 
 /* counters a sweep leaves behind (device memory, also copied to the host on request) */
 typedef struct dj_sweep_result {
@@ -183,6 +200,11 @@ int dj_pop_due(dj_engine* e, uint64_t now_ms, uint32_t cap_conts,
 int dj_sweep(dj_engine* e, uint64_t now_ms, uint32_t cap_conts, uint64_t cap_positions,
              dj_cont* d_conts, uint32_t* d_lens, uint32_t* d_max_waits, uint8_t* d_payloads,
              dj_sweep_result* d_result, dj_sweep_result* h_result);
+
+/* Copies n long messages out of the arena: message i (d_refs[i], as found in a payload row) goes to
+ * d_out + d_offsets[i] (16-byte aligned offsets; the caller sizes d_out from the lengths).  A
+ * reference that does not point into the arena is skipped. */
+int dj_fetch_long(dj_engine* e, uint32_t n, const dj_long_ref* d_refs, const uint64_t* d_offsets, uint8_t* d_out);
 
 /* Outcome of publishing, for n (or *d_n when d_n != NULL, then n is the upper bound)
  * continuations previously returned by dj_sweep / dj_pop_due; d_ok[i] != 0 (or d_ok == NULL)

@@ -97,8 +97,27 @@ class ParityDriver:
         got, want = self._canon_engine(conts, lens, mws, pay), self._canon_oracle(oc, ol, om, op_)
         assert got.keys() == want.keys(), f"popped sets differ: only engine {sorted(got.keys() - want.keys())[:10]} only oracle {sorted(want.keys() - got.keys())[:10]}"
         for k in want:
-            assert got[k] == want[k], f"continuation of {self.ids[k]} differs:\n engine {got[k]}\n oracle {want[k]}"
+            assert got[k] == want[k], f"continuation of {self.ids[k]} differs: {self._diff(got[k], want[k])}"
         return conts, oc
+
+    @staticmethod
+    def _diff(g, w):
+        """Short description of where two canonical continuations differ (messages can be long)."""
+        if g[0] != w[0]:
+            return f"head engine {g[0]} oracle {w[0]}"
+        if g[1] is None or w[1] is None:
+            return f"messages engine {g[1] is not None} oracle {w[1] is not None}"
+        out = []
+        for p, (a, b) in enumerate(zip(g[1], w[1])):
+            if a == b:
+                continue
+            if a is None or b is None:
+                out.append(f"pos {p}: engine {'missing' if a is None else len(a[0])} oracle {'missing' if b is None else len(b[0])}")
+                continue
+            first = next((i for i, (x, y) in enumerate(zip(a[0], b[0])) if x != y), min(len(a[0]), len(b[0])))
+            out.append(f"pos {p}: len {len(a[0])}/{len(b[0])} max-wait {a[1]}/{b[1]} first differing byte {first} "
+                       f"engine {a[0][first:first + 8].hex()} oracle {b[0][first:first + 8].hex()}")
+        return "; ".join(out[:6])
 
     def pop(self, now):
         conts, more = self.e.pop_due(now)

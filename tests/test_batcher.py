@@ -106,3 +106,29 @@ def test_async_answers_virtual_clock_and_limits():
         b.run(lambda now: 1 // 0)
     b.close()
     e.close()
+
+
+def test_long_messages_through_the_batcher():
+    from distributed_join_amd.batcher import Batcher
+    from distributed_join_amd.engine import Engine
+    e = Engine(capacity_barriers=256, arena_bytes=16 << 20, max_count=4, payload_stride=64, max_batch=1024,
+               max_message_bytes=3000)
+    b = Batcher(e, max_batch=64, max_wait_us=50)          # staging rows as wide as the engine's longest message
+    clock = [T0 + 1]
+    b.set_clock(lambda: clock[0])
+    fp = capi.fingerprint("big~1")
+    assert b.fork_wait(fp, 2, T0 + 10_000) == capi.DJ_FORK_CREATED
+    long_msg = bytes((i * 31 + 7) % 256 for i in range(3000))
+    assert b.join_wait(fp, 1, long_msg) == capi.DJ_JOIN_WAITING
+    assert b.join_wait(fp, 0, b"x" * 3001) == capi.DJ_JOIN_TOO_LONG
+    assert b.join_wait(fp, 0, b"short") == capi.DJ_JOIN_COMPLETE
+
+    def sweep(now):
+        conts, lens, _, pay, more = e.sweep(now)
+        return conts, lens, pay
+
+    conts, lens, pay = b.run(sweep)
+    assert len(conts) == 1 and lens.tolist() == [5, 3000]
+    assert bytes(pay[0][:5]) == b"short" and bytes(pay[1][:3000]) == long_msg
+    b.close()
+    e.close()

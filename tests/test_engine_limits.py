@@ -132,3 +132,36 @@ def test_misaligned_or_null_pointers_are_refused():
     with pytest.raises(EngineError, match="misaligned"):
         e.fork_batch_dev(1, buf[4:], st)
     e.close()
+
+
+def test_long_messages_when_the_arena_runs_out():
+    """Messages beyond the inline row need a block each; when the arena cannot give one the event is
+    answered NO_SPACE and its position holds an empty message (the barrier stays consistent and still
+    completes).  Blocks come back when the barrier is deleted."""
+    # slabs of count 4: 1 + 4 units; 8 barriers = 40 units; blocks of 4 KiB = 64 units each: room for 3
+    e = _engine(capacity_barriers=64, arena_bytes=64 * (1 + 40 + 3 * 64 + 10), max_count=4, payload_stride=64,
+                max_message_bytes=4096, max_batch=256)
+    ids = [f"big~{k}" for k in range(8)]
+    assert (e.fork_batch(_forks(ids, 4)) == capi.DJ_FORK_CREATED).all()
+    msg = np.arange(5 * 4096, dtype=np.uint32).view(np.uint8)[:5 * 4096].reshape(5, 4096).copy()
+    st = e.join_batch(_joins(ids[:5], 0, length=4096), msg, T0)
+    assert sorted(st.tolist()) == [capi.DJ_JOIN_WAITING] * 3 + [capi.DJ_JOIN_NO_SPACE] * 2
+    for k in range(5):
+        meta, lens, _, pay = e.snapshot_one(*capi.fingerprint(ids[k]))
+        if st[k] == capi.DJ_JOIN_WAITING:
+            assert int(lens[0]) == 4096 and bytes(pay[0][:4096]) == msg[k].tobytes()
+        else:
+            assert int(lens[0]) == 0
+    # a short message over a long one gives the block back at once: the next long message fits
+    kept = [k for k in range(5) if st[k] == capi.DJ_JOIN_WAITING]
+    assert e.join_batch(_joins([ids[kept[0]]], 0, length=8), np.zeros((1, 16), np.uint8), T0 + 1).tolist() == [capi.DJ_JOIN_WAITING]
+    assert e.join_batch(_joins([ids[6]], 1, length=4000), msg[:1], T0 + 2).tolist() == [capi.DJ_JOIN_WAITING]
+    _, lens, _, pay = e.snapshot_one(*capi.fingerprint(ids[6]))
+    assert lens.tolist() == [capi.DJ_NIL, 4000, capi.DJ_NIL, capi.DJ_NIL] and bytes(pay[1][:4000]) == msg[0].tobytes()[:4000]
+    # delete everything: all units are free again
+    conts, *_ = e.sweep(T0 + 120_000)
+    assert len(conts) == 8
+    assert (e.ack_batch(conts, None, T0 + 120_000) == capi.DJ_ACK_DONE).all()
+    s = e.stats()
+    assert s["live"] == 0 and s["arena_units_free"] == s["arena_units_used"] - 1
+    e.close()

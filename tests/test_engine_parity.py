@@ -10,6 +10,7 @@ publish whose metadata snapshot carries another :count than the live barrier.
 import numpy as np
 import pytest
 
+from distributed_join_amd import capi
 from tests.parity import ParityDriver, payload_bytes
 
 pytestmark = pytest.mark.gpu
@@ -17,19 +18,22 @@ T0 = 1_700_000_000_000
 
 
 def make_pair(oracle_lib, ids, stride, max_count=999, capacity=None, arena=256 << 20, max_batch=1 << 16, delay=2000,
-              hot_mode=-1):
+              hot_mode=-1, max_message=0):
     from distributed_join_amd.engine import Engine
     e = Engine(capacity_barriers=capacity or max(len(ids), 64), arena_bytes=arena, max_count=max_count,
                payload_stride=stride, max_batch=max_batch, check_publish_delay_ms=delay, host_cap_conts=1 << 16,
-               host_cap_positions=1 << 20)
+               host_cap_positions=1 << 20, max_message_bytes=max_message)
     e.set_hot_path(hot_mode)     # -1 automatic, 0 serial walk, 1 parallel kernels for long chains
-    o = oracle_lib.Oracle(ids, max_count=max_count, payload_stride=stride, check_publish_delay_ms=delay)
+    # the oracle keeps whole messages: its row width is the longest message the engine accepts
+    o = oracle_lib.Oracle(ids, max_count=max_count, payload_stride=max(stride, max_message), check_publish_delay_ms=delay)
     return e, o, ParityDriver(e, o, ids)
 
 
-def run_oplog(d, rng, n_barriers, counts, stride, rounds, batch, hot=None, var_len=False, unknown=0, on_round=None):
+def run_oplog(d, rng, n_barriers, counts, stride, rounds, batch, hot=None, var_len=False, unknown=0, on_round=None,
+              long_to=None):
     """counts[b] is fixed per barrier index (a re-fork keeps it).  on_round(r) runs after round r
-    (continuations may be in flight at that moment)."""
+    (continuations may be in flight at that moment).  long_to: longest accepted message when the
+    engine takes messages beyond its inline row (40 % of the messages are then longer than a row)."""
     now = T0
     forked = np.zeros(n_barriers, dtype=bool)
     version = 0
@@ -53,11 +57,15 @@ def run_oplog(d, rng, n_barriers, counts, stride, rounds, batch, hot=None, var_l
             pos = (rng.random(n) * cnt).astype(np.int64)
             pos[rng.random(n) < 0.02] += 1000          # out of range
             version += 1
-            pitch = stride + 16 if var_len else stride
+            top = long_to if long_to else stride
+            pitch = top + 16 if (var_len or long_to) else stride
             pay = payload_bytes(jb, pos % 1024, np.full(n, version) + np.arange(n), pitch)
-            ln = rng.integers(0, stride + 1, n) if var_len else np.full(n, stride)
-            if var_len:
-                ln[rng.random(n) < 0.01] = stride + 5   # too long
+            ln = rng.integers(0, stride + 1, n) if (var_len or long_to) else np.full(n, stride)
+            if long_to:
+                big = rng.random(n) < 0.4
+                ln[big] = rng.integers(stride + 1, long_to + 1, int(big.sum()))
+            if var_len or long_to:
+                ln[rng.random(n) < 0.01] = top + 5      # too long
             jmw = np.where(rng.random(n) < 0.2, rng.integers(1, 5, n), 0)
             d.join(jb, pos, ln, jmw, pay, now)
             if rng.random() < 0.7:
@@ -220,3 +228,49 @@ def test_checkpoint_load_rejects_other_geometry(tmp_path):
     with pytest.raises(RuntimeError, match="checkpoint"):
         b.checkpoint_load(junk)
     b.close()
+
+
+def test_messages_longer_than_a_row(oracle_lib, tmp_path):
+    """Engine with 64-byte inline rows that accepts messages up to 2 KiB: 40 % of the messages take a
+    block of their own.  Overwrites (same and other size class, long over short and back), re-forks,
+    failed publishes with retries, drops, recover, and a save / restore into a new engine every
+    fourth round.  At the end every barrier is completed and deleted: every arena unit ever handed out
+    must be back in a free list (nothing leaked, nothing freed twice)."""
+    from distributed_join_amd.engine import Engine
+    rng = np.random.default_rng(99)
+    nb, stride, M = 250, 64, 2048
+    ids = [f"long{b}~t" for b in range(nb)]
+    counts = rng.integers(1, 24, nb)
+    counts[:4] = [70, 130, 1, 64]
+    e, o, d = make_pair(oracle_lib, ids, stride, capacity=nb, arena=64 << 20, max_message=M)
+    kw = dict(capacity_barriers=nb, arena_bytes=64 << 20, max_count=999, payload_stride=stride, max_batch=1 << 16,
+              check_publish_delay_ms=2000, host_cap_conts=1 << 16, host_cap_positions=1 << 20, max_message_bytes=M)
+    path = tmp_path / "long.ckpt"
+
+    def swap(r):
+        if r % 4 != 3:
+            return
+        d.e.checkpoint_save(path)
+        before = d.e.stats()
+        d.e.close()
+        d.e = Engine(**kw)
+        d.e.checkpoint_load(path)
+        assert d.e.stats() == before
+
+    run_oplog(d, rng, nb, counts, stride, rounds=12, batch=400, long_to=M, on_round=swap)
+    # wind down: fork everything again (resets what is left), complete every barrier, publish, ack
+    now = T0 + 10_000_000
+    d.fork(np.arange(nb), counts, np.full(nb, now + 50_000))
+    for b0 in range(0, nb, 50):
+        bb = np.repeat(np.arange(b0, min(b0 + 50, nb)), counts[b0:b0 + 50])
+        pp = np.concatenate([np.arange(c) for c in counts[b0:b0 + 50]])
+        ln = rng.integers(0, M + 1, len(bb))
+        d.join(bb, pp, ln, np.zeros(len(bb), np.int64), payload_bytes(bb, pp, np.full(len(bb), 7777), M + 16), now)
+    ec, oc = d.sweep(now)
+    assert len(ec) == nb
+    out = d.ack(ec, oc, lambda k: True, now)
+    assert set(out.values()) == {capi.DJ_ACK_DONE}
+    s = d.e.stats()
+    assert s["live"] == 0
+    assert s["arena_units_free"] == s["arena_units_used"] - 1, s       # unit 0 is reserved
+    d.e.close()
