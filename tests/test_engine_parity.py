@@ -230,7 +230,8 @@ def test_checkpoint_load_rejects_other_geometry(tmp_path):
     b.close()
 
 
-def test_messages_longer_than_a_row(oracle_lib, tmp_path):
+@pytest.mark.parametrize("hot_mode", [-1, 1])
+def test_messages_longer_than_a_row(oracle_lib, tmp_path, hot_mode):
     """Engine with 64-byte inline rows that accepts messages up to 2 KiB: 40 % of the messages take a
     block of their own.  Overwrites (same and other size class, long over short and back), re-forks,
     failed publishes with retries, drops, recover, and a save / restore into a new engine every
@@ -242,7 +243,7 @@ def test_messages_longer_than_a_row(oracle_lib, tmp_path):
     ids = [f"long{b}~t" for b in range(nb)]
     counts = rng.integers(1, 24, nb)
     counts[:4] = [70, 130, 1, 64]
-    e, o, d = make_pair(oracle_lib, ids, stride, capacity=nb, arena=64 << 20, max_message=M)
+    e, o, d = make_pair(oracle_lib, ids, stride, capacity=nb, arena=64 << 20, max_message=M, hot_mode=hot_mode)
     kw = dict(capacity_barriers=nb, arena_bytes=64 << 20, max_count=999, payload_stride=stride, max_batch=1 << 16,
               check_publish_delay_ms=2000, host_cap_conts=1 << 16, host_cap_positions=1 << 20, max_message_bytes=M)
     path = tmp_path / "long.ckpt"
@@ -254,10 +255,12 @@ def test_messages_longer_than_a_row(oracle_lib, tmp_path):
         before = d.e.stats()
         d.e.close()
         d.e = Engine(**kw)
+        d.e.set_hot_path(hot_mode)
         d.e.checkpoint_load(path)
         assert d.e.stats() == before
 
-    run_oplog(d, rng, nb, counts, stride, rounds=12, batch=400, long_to=M, on_round=swap)
+    # with the parallel long-chain kernels forced on, a third of the joins go to barrier 1 (count 130)
+    run_oplog(d, rng, nb, counts, stride, rounds=12, batch=400, long_to=M, on_round=swap, hot=1 if hot_mode == 1 else None)
     # wind down: fork everything again (resets what is left), complete every barrier, publish, ack
     now = T0 + 10_000_000
     d.fork(np.arange(nb), counts, np.full(nb, now + 50_000))
