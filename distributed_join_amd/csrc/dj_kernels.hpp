@@ -265,32 +265,31 @@ __global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint
         if (cur != 0) {
             is_complex = true;
         } else {
-            // sort by event index (array order); unused entries carry 0xFFFFFFFF and sink to the end
-#pragma unroll
-            for (int a = 0; a < CHAIN_REG; ++a)
-#pragma unroll
-                for (int b = 0; b + 1 < CHAIN_REG - a; ++b)
-                    if (idx[b] > idx[b + 1]) {
-                        uint32_t ti = idx[b]; idx[b] = idx[b + 1]; idx[b + 1] = ti;
-                        uint64_t tn = nd[b]; nd[b] = nd[b + 1]; nd[b + 1] = tn;
-                    }
             ReplayState r;
             r.count = count;
             r.bits = count > 64 ? 0 : bits0;
             r.arrived = count > 64 ? (uint32_t)bits0 : (uint32_t)__popcll(bits0);
             r.pa = NQ; r.pa_loaded = false; r.pa_dirty = false; r.enq = false;
+            // Replay in array order: every round picks the smallest event index not yet replayed (unused
+            // entries carry 0xFFFFFFFF).  The body exists once (a real loop), the scans over the register
+            // arrays are unrolled with constant indices: few live registers, no scratch.
+            uint32_t done = 0;
+#pragma unroll 1
+            for (int round = 0; round < m; ++round) {
+                uint32_t best = 0xFFFFFFFFu, bk = 0;
+                uint64_t bn = 0;
 #pragma unroll
-            for (int k = 0; k < CHAIN_REG; ++k) {
-                if (k < m) {
-                    const uint32_t pos = node_pos(nd[k]);
-                    const int32_t st = replay_one(t, s, slab, r, pos, node_mw(nd[k]), now);
-                    if (st != DJ_JOIN_WAITING) status[idx[k]] = st;
-                    bool last = true;   // last writer of its position inside the batch
+                for (int k = 0; k < CHAIN_REG; ++k)
+                    if (!(done & (1u << k)) && idx[k] < best) { best = idx[k]; bk = (uint32_t)k; bn = nd[k]; }
+                done |= 1u << bk;
+                const uint32_t pos = node_pos(bn);
+                const int32_t st = replay_one(t, s, slab, r, pos, node_mw(bn), now);
+                if (st != DJ_JOIN_WAITING) status[best] = st;
+                bool last = true;   // last writer of its position inside the batch: no later event has it
 #pragma unroll
-                    for (int j = k + 1; j < CHAIN_REG; ++j)
-                        if (j < m && node_pos(nd[j]) == pos) last = false;
-                    if (!last) w.dst[idx[k]] = NODST;
-                }
+                for (int k = 0; k < CHAIN_REG; ++k)
+                    if (!(done & (1u << k)) && idx[k] != 0xFFFFFFFFu && node_pos(nd[k]) == pos) last = false;
+                if (!last) w.dst[best] = NODST;
             }
             sl->bits = count > 64 ? (uint64_t)r.arrived : r.bits;
             sl->join_ts = now;                              // SET <id>:join-ts, redis.clj:136
