@@ -206,10 +206,11 @@ def main():
     router = None
     if routed:
         from distributed_join_amd.router import Router
-        router = Router(eng, dist.group.WORLD, max_send=batch, max_recv=max(recv_cap, nb * 2), pitch=pitch)
+        router = Router(eng, dist.group.WORLD, max_send=batch, max_recv=max(recv_cap, nb * 2), pitch=pitch, depth=4)
 
     now = [1_700_000_000_000]
     pending = []         # routing handles of the next batches (up to two), started while the current one is applied
+    pending_fork = []    # routing handle of the next job's forks, started during the last step of the current job
 
     def start_route(k):
         lo = (k % steps_per_job) * batch
@@ -223,7 +224,8 @@ def main():
             if router is None:
                 eng.fork_batch_dev(nb, fork_recs, d_status)
             else:
-                r_recs, _, n_in, h = router.route(fork_recs, None, nb)
+                h = pending_fork.pop(0) if pending_fork else router.start(fork_recs, None, nb)
+                r_recs, _, n_in = router.finish(h)
                 eng.fork_batch_dev(n_in, r_recs, d_status)
                 router.release(h)
         lo = s * batch
@@ -240,12 +242,14 @@ def main():
         eng.ack_batch_dev(cap_conts, d_res, d_conts, None, now[0], d_ack_status)
         if router is not None:
             # the whole step is queued on the engine's stream; now the host can afford to wait for the
-            # next batch's bucket sizes (the routing runs on the router's stream meanwhile)
-            # (the routing runs on the router's stream meanwhile).  Two batches ahead: the exchange of
-            # batch k+1 was started a step ago, so the engine never waits for the host.
+            # next batches' bucket sizes (the routing runs on the router's stream meanwhile).  Two batches
+            # ahead: the exchange of batch k+1 was started a step ago, so the engine never waits for the
+            # host.  The next job's forks are routed during the current job's last step.
             for ahead in range(1, prefetch + 1):
                 if len(pending) < ahead:
                     pending.append(start_route(k + len(pending) + 1))
+            if prefetch and s == steps_per_job - 1 and not pending_fork:
+                pending_fork.append(router.start(fork_recs, None, nb))
         if a.hot_frac > 0:
             eng.sync()      # a host that reads each batch's statuses; also lets the engine see the previous
                             # batch's longest chain in time to pick the parallel hot-barrier kernels
