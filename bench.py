@@ -40,9 +40,20 @@ def parse():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--hot-frac", type=float, default=0.0,
                     help="experiment: retarget this fraction of the joins to ONE barrier (hot key, replays)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="functional rehearsal of the N>1 path on a box with ONE GPU: all ranks share device 0 and the "
+                         "collectives go over gloo (RCCL refuses two ranks on one device); not a measurement")
     ap.add_argument("--route", action="store_true",
                     help="run the multi-GPU routing path (partition + all-to-all) even with one rank")
     return ap.parse_args()
+
+
+DEBUG = bool(os.environ.get("DJ_BENCH_DEBUG"))
+
+
+def dbg(*a):
+    if DEBUG:
+        print(f"{time.time() % 1000:8.3f} [rank {os.environ.get('RANK', '0')}]", *a, file=sys.stderr, flush=True)
 
 
 def make_ids(lo, hi):
@@ -141,13 +152,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     routed = world > 1 or a.route
-    if world > 1:
+    if world > 1 and a.rehearse_on_one_gpu:
+        local = 0
+        dist.init_process_group("gloo")
+    elif world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     elif a.route:
         dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{29400 + os.getpid() % 500}", rank=0, world_size=1,
                                 device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    dbg("process group up, device", local)
 
     nb, c, P = a.barriers, a.count, a.payload
     batch = nb                      # events per step per GPU
@@ -208,6 +223,7 @@ def main():
         from distributed_join_amd.router import Router
         router = Router(eng, dist.group.WORLD, max_send=batch, max_recv=max(recv_cap, nb * 2), pitch=pitch, depth=4)
 
+    dbg("engine and router ready")
     now = [1_700_000_000_000]
     pending = []         # routing handles of the next batches (up to two), started while the current one is applied
     pending_fork = []    # routing handle of the next job's forks, started during the last step of the current job
@@ -220,6 +236,7 @@ def main():
         """One step: (fork at job start) + join batch + sweep + ack."""
         s = k % steps_per_job
         now[0] += 1
+        dbg("step", k)
         if s == 0:
             if router is None:
                 eng.fork_batch_dev(nb, fork_recs, d_status)
@@ -292,20 +309,25 @@ def main():
     # every kernel on the engine's stream ------------------------------------------------------------
     kernels = {}
     roofline = None
-    if not a.no_profile and rank == 0:
+    acc = {}
+    if not a.no_profile:
+        # every rank runs these steps (the routed path is a collective); only rank 0 times its kernels
         done = a.steps
         # finish the job in flight so the profiled job starts on an empty table
         while done % steps_per_job:
             step(done, prefetch=0)
             done += 1
         eng.sync()
-        eng.profile_enable(True)
-        acc = {}
+        if rank == 0:
+            eng.profile_enable(True)
         for k in range(steps_per_job):
             step(k, prefetch=0)
-            for name, ms in eng.profile_read().items():
-                acc.setdefault(name, []).append(ms)
-        eng.profile_enable(False)
+            if rank == 0:
+                for name, ms in eng.profile_read().items():
+                    acc.setdefault(name, []).append(ms)
+        if rank == 0:
+            eng.profile_enable(False)
+    if acc:
         fired_job = nb   # per rank at N=1; at N>1 about nb
         units = {   # algorithmic bytes per launch: per-unit figure x units (kernels table)
             "join_link": (96, batch), "join_resolve": (16, batch), "join_copy": (2 * P, batch),
@@ -360,7 +382,8 @@ def main():
                                    f"no timeouts; step = {batch} joins + sweep/gather + ack, fork of {nb} barriers every "
                                    f"{steps_per_job} steps", "barriers_per_gpu": nb, "count": c, "payload_bytes": P,
                        "batch": batch,
-                       "sharding": "none" if not routed else f"fingerprint hash over {world} GPU(s), partition + all-to-all"},
+                       "sharding": "none" if not routed else f"fingerprint hash over {world} GPU(s), partition + all-to-all"
+                                   + (" (REHEARSAL: all ranks on one GPU, gloo)" if a.rehearse_on_one_gpu else "")},
             "continuations_per_s": float(fired.item()) / elapsed_s,
             "continuations_fired": int(fired.item()),
             "gpu_stream_ms": gpu_ms,

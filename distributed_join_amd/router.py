@@ -19,7 +19,18 @@ the host:
     engine.join_batch_dev(n_in, recs_in, pay_in, ...)
     router.release(h)                        # after the batch's kernels are queued: buffers may be reused
 """
+import os
+import sys
+
 import numpy as np
+
+_DEBUG = bool(os.environ.get("DJ_BENCH_DEBUG"))
+
+
+def _dbg(*a):
+    if _DEBUG:
+        import time
+        print(f"{time.time() % 1000:8.3f} [router rank {os.environ.get('RANK', '0')}]", *a, file=sys.stderr, flush=True)
 
 
 def owner_of_np(fp_hi, n_ranks):
@@ -45,8 +56,10 @@ def exchange_rows(dist, group, recs_sorted, pay_sorted, send_counts, recv_counts
     n_in, n_out = sum(recv_counts), sum(send_counts)
     if n_in > recv_recs.shape[0]:
         raise RuntimeError(f"router: {n_in} incoming records exceed the receive buffer ({recv_recs.shape[0]})")
+    _dbg("records a2a", n_out, "->", n_in)
     dist.all_to_all_single(recv_recs[:n_in], recs_sorted[:n_out], output_split_sizes=recv_counts,
                            input_split_sizes=list(send_counts), group=group)
+    _dbg("records done")
     if pay_sorted is not None:
         dist.all_to_all_single(recv_pay[:n_in], pay_sorted[:n_out], output_split_sizes=recv_counts,
                                input_split_sizes=list(send_counts), group=group)
@@ -85,6 +98,10 @@ class Router:
         self.engine_stream = engine.torch_stream()
         self.slots = [_Slot(torch, dev, max_send, max_recv, self.pitch) for _ in range(max(2, int(depth)))]
         self.turn = 0
+        # gloo (tests, rehearsals on one GPU) moves device tensors through worker threads without
+        # blocking the caller, and several such exchanges in flight can pair up differently on two
+        # ranks; with gloo the rows are therefore staged through host memory, one blocking call at a time
+        self.host_staged = dist.get_backend(group) == "gloo"
 
     def start(self, d_recs, d_payloads, n):
         """Begin routing n records (rows of the (n, 4) int64 tensor d_recs: dj_join_rec or dj_fork_rec)
@@ -101,17 +118,38 @@ class Router:
             self.e.partition_joins_dev(n, self.world, d_recs, d_payloads, self.pitch, s.recs_sorted,
                                        s.pay_sorted if s.has_pay else None, s.origin, s.counts,
                                        stream_ptr=self.stream.cuda_stream)
+            if self.host_staged:
+                self._exchange_host_staged(s, n)
+                return s
             # bucket sizes travel rank to rank on the device; ONE read-back brings both sides' sizes to the host
             w = self.world
+            _dbg("partition queued, exchanging bucket sizes")
             self.dist.all_to_all_single(s.counts_in[:w], s.counts[:w], group=self.group)
             s.h_counts[:64].copy_(s.counts, non_blocking=True)
             s.h_counts[64:].copy_(s.counts_in, non_blocking=True)
             self.stream.synchronize()                 # waits for the router's stream only
             hc = s.h_counts.tolist()
+            _dbg("bucket sizes", hc[:w], hc[64:64 + w])
             s.n_in, _ = exchange_rows(self.dist, self.group, s.recs_sorted, s.pay_sorted if s.has_pay else None,
                                       hc[:w], hc[64:64 + w], s.recv_recs, s.recv_pay)
             s.ready.record(self.stream)
+            _dbg("rows exchanged")
         return s
+
+    def _exchange_host_staged(self, s, n):
+        torch, w = self.torch, self.world
+        self.stream.synchronize()
+        counts = [int(x) for x in s.counts[:w].cpu().tolist()]
+        n_out = sum(counts)
+        rs = s.recs_sorted[:n_out].cpu()
+        ps = s.pay_sorted[:n_out].cpu() if s.has_pay else None
+        rr = torch.empty((s.recv_recs.shape[0], 4), dtype=torch.int64)
+        rp = torch.empty((s.recv_pay.shape[0], self.pitch), dtype=torch.uint8) if s.has_pay else None
+        s.n_in, _ = exchange(self.dist, self.group, rs, ps, counts, rr, rp)
+        s.recv_recs[:s.n_in].copy_(rr[:s.n_in], non_blocking=False)
+        if s.has_pay:
+            s.recv_pay[:s.n_in].copy_(rp[:s.n_in], non_blocking=False)
+        s.ready.record(self.stream)
 
     def finish(self, s):
         """-> (records for this rank, messages for this rank or None, n_received).  The engine's stream

@@ -1,0 +1,38 @@
+"""bench.py's N>1 flow (routing two batches ahead, fork routing during a job's last step, the per-kernel
+leg on every rank) rehearsed with two ranks that share the one GPU of the box; the collectives go over
+gloo because RCCL refuses two ranks on one device.  Checks the bookkeeping, not the speed."""
+import json
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NB, STEPS = 16384, 16
+
+
+def worker(rank, port, out_dir):
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port)})
+    sys.path.insert(0, ROOT)
+    sys.argv = ["bench.py", "--gpus", "2", "--steps", str(STEPS), "--warmup", "8", "--barriers", str(NB),
+                "--rehearse-on-one-gpu", "--no-cpu-baseline"]
+    sys.stdout = open(os.path.join(out_dir, f"out_{rank}.txt"), "w")
+    import bench
+    bench.main()
+    sys.stdout.flush()
+
+
+def test_bench_with_two_ranks_on_one_gpu(tmp_path):
+    import torch.multiprocessing as mp
+    port = 33500 + os.getpid() % 2000
+    mp.spawn(worker, args=(port, str(tmp_path)), nprocs=2, join=True)
+    lines = [ln for ln in open(tmp_path / "out_0.txt").read().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    assert not [ln for ln in open(tmp_path / "out_1.txt").read().splitlines() if ln.startswith("{")]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == STEPS and out["scaling"] == "weak"
+    # every rank generates NB barriers per job; 16 steps = 2 jobs; every barrier fires exactly once
+    assert out["continuations_fired"] == 2 * NB * (STEPS // 8)
+    assert out["value"] > 0 and out["roofline"]["kernel"] in out["kernels"]
