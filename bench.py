@@ -329,7 +329,9 @@ def main():
             eng.profile_enable(False)
     if acc:
         fired_job = nb   # per rank at N=1; at N>1 about nb
-        units = {   # algorithmic bytes per launch: per-unit figure x units (kernels table)
+        units = {   # algorithmic bytes per launch: per-unit figure x units.  Per event: 32 B header + 64 B table line
+            # (link), 16 B presence update (resolve), message in + out (copy); per fired barrier 96 + 2cP;
+            # per inserted barrier 160; per slot scanned 16
             "join_link": (96, batch), "join_resolve": (16, batch), "join_copy": (2 * P, batch),
             "join_complex": (0, 0), "pop": (16, eng.stats()["slots"]), "gather": (96 + 2 * c * P, fired_job / steps_per_job),
             "fork_claim": (96, nb), "fork_apply": (64, nb), "ack": (128, fired_job / steps_per_job),
@@ -361,7 +363,7 @@ def main():
         torch.cuda.synchronize()
         roofline["measured_copy_GBps"] = round(5 * 2 * (1 << 30) / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)
         del src, dst
-        # the whole join path (link + resolve + copy) against SURVEY's per-event figure 112 + 2P
+        # the whole join path (link + resolve + copy) against its per-event figure 112 + 2P
         jt = sum(kernels[k]["avg_ms"] for k in ("join_link", "join_resolve", "join_complex", "join_copy") if k in kernels)
         roofline["join_path"] = {"alg_bytes_per_event": 112 + 2 * P, "ms_per_batch": round(jt, 4),
                                  "achieved_GBps": round((112 + 2 * P) * batch / (jt * 1e-3) / 1e9, 1),
