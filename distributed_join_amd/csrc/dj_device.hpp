@@ -329,56 +329,82 @@ __device__ inline uint32_t wave_slab_alloc(const Table& t, bool want, uint32_t k
     return slab;
 }
 
-// Block-cooperative form for kernels where (almost) every thread allocates the same class:
-// ONE ring pop and ONE bump add per block for the block's first class; threads of other
-// classes go through the wave path.  Every thread of the block must call it.
-// lds: 24 words of shared memory.
+// Rank of every lane with pred inside its class, counted over the whole block: one LDS atomic per
+// wave and class.  cnt: NUM_CLASSES words of shared memory, zeroed, barrier before and after by the caller.
+__device__ inline uint32_t block_class_rank(bool pred, uint32_t k, uint32_t* cnt) {
+    const uint32_t lane = lane_id();
+    uint32_t rank = 0;
+    uint64_t todo = __ballot(pred);
+    while (todo) {
+        const int l0 = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t k0 = __shfl(k, l0);
+        const uint64_t grp = __ballot(pred && k == k0);
+        uint32_t base = 0;
+        if ((int)lane == l0) base = atomicAdd(&cnt[k0], (uint32_t)__popcll(grp));
+        base = __shfl(base, l0);
+        if (pred && k == k0) rank = base + (uint32_t)__popcll(grp & ((1ull << lane) - 1));
+        todo &= ~grp;
+    }
+    return rank;
+}
+
+constexpr int BLOCK_SLAB_LDS = 4 * NUM_CLASSES + 4;     // words of shared memory the two block helpers need
+
+// Block-cooperative form: ONE ring pop per size class and ONE bump add per block, whatever mix of
+// classes the block's threads ask for (barriers of many sizes in one batch must not fall back to an
+// atomic per wave and class).  Every thread of the block must call it.  lds: BLOCK_SLAB_LDS words.
 __device__ inline uint32_t block_slab_alloc(const Table& t, bool want, uint32_t k, uint32_t* lds) {
-    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    if (threadIdx.x == 0) lds[16] = 0xFFFFFFFFu;
+    uint32_t* cnt = lds;                         // requests per class
+    uint32_t* head = lds + NUM_CLASSES;          // ring position of the class's pop
+    uint32_t* got = lds + 2 * NUM_CLASSES;       // how many of them the ring could serve
+    uint32_t* off = lds + 3 * NUM_CLASSES;       // unit offset of the class inside the block's bump reservation
+    uint32_t* base = lds + 4 * NUM_CLASSES;      // [0..1] the reservation's first unit, [2] anything requested
+    if (threadIdx.x < NUM_CLASSES) cnt[threadIdx.x] = 0;
     __syncthreads();
-    if (want) atomicMin(&lds[16], k);
+    const uint32_t rank = block_class_rank(want, k, cnt);
     __syncthreads();
-    const uint32_t kb = lds[16];
-    if (kb == 0xFFFFFFFFu) return 0;                       // nobody allocates (uniform across the block)
-    const bool fast = want && k == kb;
-    const uint64_t m = __ballot(fast);
-    if (lane == 0) lds[wv] = (uint32_t)__popcll(m);
+    if (threadIdx.x < NUM_CLASSES) {
+        const uint32_t c = threadIdx.x, m = cnt[c];
+        uint32_t h = 0;
+        int g = 0;
+        if (m) {
+            const unsigned int snap = t.ring_tail_snap[c];
+            h = a_add(&t.ring_head[c], m);
+            const int avail = (int)(snap - h);
+            g = avail < 0 ? 0 : (avail > (int)m ? (int)m : avail);
+            if (g < (int)m) a_add(&t.ring_head[c], (unsigned int)(g - (int)m));    // give back the overshoot
+        }
+        head[c] = h;
+        got[c] = (uint32_t)g;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (uint32_t v = 0; v < nw; ++v) { const uint32_t c = lds[v]; lds[v] = tot; tot += c; }
-        uint32_t h = 0;
-        int got = 0;
-        const unsigned int snap = t.ring_tail_snap[kb];
-        h = a_add(&t.ring_head[kb], tot);
-        const int avail = (int)(snap - h);
-        got = avail < 0 ? 0 : (avail > (int)tot ? (int)tot : avail);
-        if (got < (int)tot) a_add(&t.ring_head[kb], (unsigned int)(got - (int)tot));    // give back the overshoot
-        unsigned long long base = 0;
-        const uint32_t rest = tot - (uint32_t)got;
-        if (rest) base = a_add(t.bump, (unsigned long long)rest * slab_units(kb, t.stride));
-        lds[17] = h;
-        lds[18] = (uint32_t)got;
-        lds[19] = (uint32_t)base;
-        lds[20] = (uint32_t)(base >> 32);
+        unsigned long long total = 0;
+        uint32_t any = 0;
+        for (uint32_t c = 0; c < NUM_CLASSES; ++c) {
+            off[c] = (uint32_t)total;
+            total += (unsigned long long)(cnt[c] - got[c]) * slab_units(c, t.stride);
+            any |= cnt[c];
+        }
+        const unsigned long long b = total ? a_add(t.bump, total) : 0ull;
+        base[0] = (uint32_t)b;
+        base[1] = (uint32_t)(b >> 32);
+        base[2] = any;
     }
     __syncthreads();
     uint32_t slab = 0;
-    if (fast) {
-        const uint32_t rank = lds[wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-        const uint32_t h = lds[17], got = lds[18];
-        if (rank < got) {
-            slab = t.ring[kb][(h + rank) & (t.ring_cap[kb] - 1)];
+    if (want) {
+        if (rank < got[k]) {
+            slab = t.ring[k][(head[k] + rank) & (t.ring_cap[k] - 1)];
         } else {
-            const uint32_t units = slab_units(kb, t.stride);
-            const unsigned long long u = (((unsigned long long)lds[20] << 32) | lds[19]) + (unsigned long long)(rank - got) * units;
+            const uint32_t units = slab_units(k, t.stride);
+            const unsigned long long u = (((unsigned long long)base[1] << 32) | base[0]) + off[k] +
+                                         (unsigned long long)(rank - got[k]) * units;
             if (u + units <= t.arena_units) slab = (uint32_t)u;
         }
     }
     __syncthreads();
-    const uint32_t other = wave_slab_alloc(t, want && !fast, k);
-    return fast ? slab : other;
+    return slab;
 }
 
 // Returns the slabs of lanes with has (class k) to the free rings.
@@ -399,36 +425,24 @@ __device__ inline void wave_slab_free(const Table& t, bool has, uint32_t k, uint
     }
 }
 
-// Block-cooperative form: ONE ring push per block for the block's dominant class (acks of a sweep
-// free thousands of slabs of one class; a push per wave would queue up on the ring's tail word),
-// other classes go through the wave path.  Every thread of the block must call it.
-// lds: 24 words of shared memory.
+// Block-cooperative form: ONE ring push per size class and block (acks of a sweep free thousands of
+// slabs; a push per wave would queue up on the rings' tail words).  Every thread of the block must
+// call it.  lds: BLOCK_SLAB_LDS words of shared memory.
 __device__ inline void block_slab_free(const Table& t, bool has, uint32_t k, uint32_t slab, uint32_t* lds) {
-    const uint32_t lane = lane_id(), wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    uint32_t* cnt = lds;
+    uint32_t* tail = lds + NUM_CLASSES;
     has = has && slab != 0;
-    if (threadIdx.x == 0) lds[16] = 0xFFFFFFFFu;
+    if (threadIdx.x < NUM_CLASSES) cnt[threadIdx.x] = 0;
     __syncthreads();
-    const uint64_t hm = __ballot(has);
-    if (hm && (int)lane == __ffsll((unsigned long long)hm) - 1) atomicMin(&lds[16], k);   // one candidate per wave
+    const uint32_t rank = block_class_rank(has, k, cnt);
     __syncthreads();
-    const uint32_t kb = lds[16];
-    if (kb == 0xFFFFFFFFu) return;                         // nothing to free (uniform across the block)
-    const bool fast = has && k == kb;
-    const uint64_t m = __ballot(fast);
-    if (lane == 0) lds[wv] = (uint32_t)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (uint32_t v = 0; v < nw; ++v) { const uint32_t c = lds[v]; lds[v] = tot; tot += c; }
-        lds[17] = tot ? a_add(&t.ring_tail[kb], tot) : 0u;
+    if (threadIdx.x < NUM_CLASSES) {
+        const uint32_t c = threadIdx.x;
+        tail[c] = cnt[c] ? a_add(&t.ring_tail[c], cnt[c]) : 0u;
     }
     __syncthreads();
-    if (fast) {
-        const uint32_t rank = lds[wv] + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-        t.ring[kb][(lds[17] + rank) & (t.ring_cap[kb] - 1)] = slab;
-    }
+    if (has) t.ring[k][(tail[k] + rank) & (t.ring_cap[k] - 1)] = slab;
     __syncthreads();
-    wave_slab_free(t, has && !fast, k, slab);
 }
 
 // ---- blocks for long messages ----------------------------------------------------------------

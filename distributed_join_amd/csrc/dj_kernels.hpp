@@ -44,7 +44,7 @@ constexpr int FORK_APPLY_BLOCK = 1024;
 
 __global__ void __launch_bounds__(FORK_APPLY_BLOCK) fork_apply_kernel(Table t, Work w, const dj_fork_rec* recs, uint32_t n,
                                                                       int32_t* status) {
-    __shared__ uint32_t lds[24];
+    __shared__ uint32_t lds[BLOCK_SLAB_LDS];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     // phase A (per lane): is this record the winner of its slot, and does the slot need a new slab
     bool active = false, need = false, had_long = false;
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(FORK_APPLY_BLOCK) fork_apply_kernel(Table t, W
     const uint32_t fresh = block_slab_alloc(t, need, k_new, lds);
     // a barrier that is reset gives its long-message blocks back (not when the reset is refused below)
     if (long_on) wave_release_long_each(t, had_long && !(need && fresh == 0), old_slab, k_old, 0, old_count);
-    wave_slab_free(t, need && fresh != 0, k_old, old_slab);
+    block_slab_free(t, need && fresh != 0, k_old, old_slab, lds);
     if (!active) return;
     // phase C (per lane)
     uint32_t slab = old_slab;
@@ -882,7 +882,7 @@ constexpr int ACK_BLOCK = 1024;
 
 __global__ void __launch_bounds__(ACK_BLOCK) ack_kernel(Table t, uint32_t n_max, const uint32_t* d_n, const dj_cont* conts,
                                                         const uint8_t* ok, uint64_t now, int32_t* status) {
-    __shared__ uint32_t lds[24];
+    __shared__ uint32_t lds[BLOCK_SLAB_LDS];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t n = d_n ? (*d_n < n_max ? *d_n : n_max) : n_max;
     if (blockIdx.x * blockDim.x >= n) return;          // the whole block is beyond the end
