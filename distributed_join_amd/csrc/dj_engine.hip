@@ -602,6 +602,13 @@ extern "C" int dj_ack_batch(dj_engine* e, uint32_t n, const uint32_t* d_n, const
     return DJ_OK;
 }
 
+static uint32_t recover_blocks(const dj_engine* e) {
+    uint64_t b = (e->t.mask + 1) / RECOVER_BLOCK;      // slots are a power of two >= 1024
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (uint32_t)b;
+}
+
 extern "C" int dj_recover(dj_engine* e, uint64_t now_ms, uint32_t cap, dj_cont* d_conts, int32_t* d_status,
                           dj_sweep_result* d_result, dj_sweep_result* h_result) {
     if (!e) return DJ_E_INVALID;
@@ -611,7 +618,7 @@ extern "C" int dj_recover(dj_engine* e, uint64_t now_ms, uint32_t cap, dj_cont* 
     dj_sweep_result* res = d_result ? d_result : e->d_result;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     HIP_TRY(e, hipMemsetAsync(res, 0, sizeof(dj_sweep_result), e->stream));
-    LAUNCH(e, DJ_PROF_RECOVER, (recover_kernel<<<scan_blocks(e), 256, 0, e->stream>>>(e->t, now_ms, cap, d_conts, d_status, res)));
+    LAUNCH(e, DJ_PROF_RECOVER, (recover_kernel<<<recover_blocks(e), RECOVER_BLOCK, 0, e->stream>>>(e->t, now_ms, cap, d_conts, d_status, res)));
     clamp_count_kernel<<<1, 64, 0, e->stream>>>(res, cap);
     HIP_TRY(e, hipGetLastError());
     if (h_result) {

@@ -994,18 +994,34 @@ __global__ void __launch_bounds__(ACK_BLOCK) ack_kernel(Table t, uint32_t n_max,
 
 // core/recover-unprocessed-publish-messages: ZRANGEBYSCORE backup 0 (now - delay), then the
 // 2-arity attempt-retry-publish with freshly read metadata (core.clj:153-155,193-201)
-__global__ void __launch_bounds__(256) recover_kernel(Table t, uint64_t now, uint32_t cap, dj_cont* conts,
-                                                      int32_t* status, dj_sweep_result* res) {
+constexpr int RECOVER_BLOCK = 1024;
+
+__global__ void __launch_bounds__(RECOVER_BLOCK) recover_kernel(Table t, uint64_t now, uint32_t cap, dj_cont* conts,
+                                                                int32_t* status, dj_sweep_result* res) {
+    __shared__ uint32_t lds[BLOCK_SLAB_LDS];
+    __shared__ uint32_t wave_n[RECOVER_BLOCK / 64];
+    __shared__ uint32_t out_base;
     const uint64_t nslots = t.mask + 1;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t max_score = now - t.check_publish_delay_ms;
-    // all lanes of a wave iterate together (nslots is a multiple of the grid's wave size)
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // all threads of a block iterate together (nslots is a multiple of the block size): output indices
+    // and slab frees cost one atomic per block and round
     for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < nslots; s += stride) {
         const uint64_t qv = t.q[s];
         const uint64_t ba = q_backup_at(qv);
         const bool due = qv != Q_NONE && ba <= max_score;
-        if (__ballot(due) == 0) continue;
-        const uint32_t at = wave_append(&res->n_conts, due);
+        if (__syncthreads_or(due) == 0) continue;
+        const uint64_t dm = __ballot(due);
+        if (lane == 0) wave_n[wv] = (uint32_t)__popcll(dm);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (uint32_t v = 0; v < RECOVER_BLOCK / 64; ++v) { const uint32_t c = wave_n[v]; wave_n[v] = tot; tot += c; }
+            out_base = a_add(&res->n_conts, tot);
+        }
+        __syncthreads();
+        const uint32_t at = out_base + wave_n[wv] + (uint32_t)__popcll(dm & ((1ull << lane) - 1));
         int32_t st = 0;
         bool clear = false;
         uint32_t k_old = 0, old_slab = 0;
@@ -1036,7 +1052,7 @@ __global__ void __launch_bounds__(256) recover_kernel(Table t, uint64_t now, uin
         }
         if (t.max_message > t.stride)
             wave_release_long_each(t, clear && (sl.meta & META_OVF) != 0, old_slab, k_old, 0, sl.count);
-        wave_slab_free(t, clear && old_slab != 0, k_old, old_slab);
+        block_slab_free(t, clear && old_slab != 0, k_old, old_slab, lds);
         if (clear) clear_slot(t, s);
         if (due) {
             if (at < cap) {
