@@ -127,17 +127,20 @@ struct Work {
     // hot-barrier path (barriers with long chains), see the cx_* kernels
     uint32_t* cx_keys;            // [CX_HASH] slab of a hot barrier, 0 = empty
     uint32_t* cx_val;             // [CX_HASH] its index in complex_[]
-    uint32_t* cx_fmin;            // [CX_CAP][1024] first event index per position
-    uint32_t* cx_fmax;            // [CX_CAP][1024] last event index + 1 per position
+    uint32_t* cx_off;             // [CX_CAP] where the barrier's per-position tables start in the pool, IDX_NONE = not registered
+    uint2* cx_mm;                 // [CX_POOL] per position: {first event index, last event index + 1}
     unsigned long long* cx_atmin; // [CX_CAP] smallest now + 1000 * max-wait among the barrier's events
     uint32_t* cx_cnt;             // [CX_CAP] events of the barrier in this batch
     uint32_t* cx_T;               // [CX_CAP] first event index that answers COMPLETE, IDX_NONE = none
+    uint32_t* cx_hot;             // [CX_CAP] 1 when the barrier was already flagged hot before the batch
     uint32_t* cx_nq;              // [CX_CAP] 1 when the barrier was not in the primary queue before the batch
     uint32_t cx_on;               // 1: this batch runs the parallel hot-barrier kernels
 };
-enum { C_COMPLEX = 1, C_MAXCHAIN = 2, C_COUNT = 8 };
-constexpr uint32_t CX_CAP = 4096;     // hot barriers per batch handled by the parallel path
-constexpr uint32_t CX_HASH = 16384;   // power of two, >= 2 * CX_CAP
+enum { C_COMPLEX = 1, C_MAXCHAIN = 2, C_CXPOOL = 3, C_COUNT = 8 };
+constexpr uint32_t CX_CAP = 65536;     // barriers with long chains per batch handled by the parallel path
+constexpr uint32_t CX_HASH = 262144;   // power of two, >= 2 * CX_CAP
+constexpr uint32_t CX_HOT_STRIDE = 8;  // pool entries per position of a barrier flagged hot (one 64-byte line)
+constexpr uint32_t CX_POOL = 1u << 24; // positions of all of them together (the rest takes the serial kernel)
 constexpr uint32_t IDX_NONE = 0xFFFFFFFFu;
 // sweep scratch: S_CURSOR packs both output cursors so a block takes its output range with one
 // atomic: continuations in the low 31 bits, positions above (positions * 64 B <= arena <= 256 GiB)

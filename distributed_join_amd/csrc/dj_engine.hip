@@ -240,15 +240,16 @@ static int create_impl(dj_engine* e) {
     HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 2 * C_COUNT * 4, e->stream));
     ALLOC(e, w.cx_keys, CX_HASH * 4);
     ALLOC(e, w.cx_val, CX_HASH * 4);
-    ALLOC(e, w.cx_fmin, (size_t)CX_CAP * 1024 * 4);
-    ALLOC(e, w.cx_fmax, (size_t)CX_CAP * 1024 * 4);
+    ALLOC(e, w.cx_off, CX_CAP * 4);
+    ALLOC(e, w.cx_mm, (size_t)CX_POOL * 8);
     ALLOC(e, w.cx_atmin, CX_CAP * 8);
     ALLOC(e, w.cx_cnt, CX_CAP * 4);
     ALLOC(e, w.cx_T, CX_CAP * 4);
     ALLOC(e, w.cx_nq, CX_CAP * 4);
+    ALLOC(e, w.cx_hot, CX_CAP * 4);
     w.cx_on = 0;
     HIP_TRY(e, hipHostMalloc((void**)&e->h_maxchain, 64, hipHostMallocDefault));
-    *e->h_maxchain = 0;
+    e->h_maxchain[0] = e->h_maxchain[1] = 0;
     ALLOC(e, e->d_sweep, 2 * S_COUNT * 8);
     HIP_TRY(e, hipMemsetAsync(e->d_sweep, 0, 2 * S_COUNT * 8, e->stream));
     e->ctr_bank = e->sweep_bank = 0;
@@ -471,7 +472,9 @@ extern "C" int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs
     e->w.counters = e->d_counters + e->ctr_bank * C_COUNT;
     e->w.counters_next = e->d_counters + (e->ctr_bank ^ 1) * C_COUNT;
     e->ctr_bank ^= 1;
-    e->w.cx_on = e->cx_force >= 0 ? (uint32_t)e->cx_force : (*(volatile unsigned int*)e->h_maxchain >= 256 ? 1u : 0u);
+    // h_maxchain[0] = barriers with long chains in the previous batch, [1] = its longest chain
+    const volatile unsigned int* hint = e->h_maxchain;
+    e->w.cx_on = e->cx_force >= 0 ? (uint32_t)e->cx_force : ((hint[1] >= 256 || hint[0] >= 1024) ? 1u : 0u);
     if (e->w.cx_on)
         LAUNCH(e, DJ_PROF_JOIN_LINK, (join_link_kernel<true><<<grid_for(n, LINK_BLOCK_HOT), LINK_BLOCK_HOT, 0, e->stream>>>(e->t, e->w, d_recs, n, pitch, d_status)));
     else
@@ -482,11 +485,11 @@ extern "C" int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs
     if (e->w.cx_on) {
         HIP_TRY(e, hipMemsetAsync(e->w.cx_keys, 0, CX_HASH * 4, e->stream));
         if (e->profiling) (void)hipEventRecord(e->ev_start[DJ_PROF_JOIN_COMPLEX], e->stream);
-        cx_init_kernel<<<256, 64, 0, e->stream>>>(e->t, e->w);
+        cx_init_kernel<<<CX_CAP / CX_BPB, 256, 0, e->stream>>>(e->t, e->w);
         uint32_t sb = grid_for(n, 256);
         if (sb > 4096) sb = 4096;
         cx_scan_kernel<<<sb, 256, 0, e->stream>>>(e->w, n, now_ms);
-        cx_finalize_kernel<<<256, 64, 0, e->stream>>>(e->t, e->w, now_ms);
+        cx_finalize_kernel<<<1024, 64, 0, e->stream>>>(e->t, e->w, now_ms);
         join_resolve_complex_kernel<<<256, 64, 0, e->stream>>>(e->t, e->w, now_ms, d_status);
         if (e->profiling) { (void)hipEventRecord(e->ev_stop[DJ_PROF_JOIN_COMPLEX], e->stream); e->ev_used[DJ_PROF_JOIN_COMPLEX] = 1; }
     } else {
@@ -498,7 +501,7 @@ extern "C" int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs
     else if (lanes <= 16) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<16>(e, n, d_recs, d_payloads, pitch, d_status));
     else if (lanes <= 32) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<32>(e, n, d_recs, d_payloads, pitch, d_status));
     else LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<64>(e, n, d_recs, d_payloads, pitch, d_status));
-    HIP_TRY(e, hipMemcpyAsync(e->h_maxchain, &e->w.counters[C_MAXCHAIN], 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->h_maxchain, &e->w.counters[C_COMPLEX], 8, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipGetLastError());
     return DJ_OK;
 }
@@ -858,7 +861,7 @@ extern "C" int dj_checkpoint_load(dj_engine* e, const char* path) {
     HIP_TRY(e, hipMemset(e->d_sweep, 0, 2 * S_COUNT * 8));
     e->used_upper = h.used_upper;
     e->claimed_since_compact = 0;
-    *e->h_maxchain = 0;
+    e->h_maxchain[0] = e->h_maxchain[1] = 0;
     return DJ_OK;
 }
 

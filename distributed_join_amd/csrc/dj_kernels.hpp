@@ -309,13 +309,14 @@ __global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint
 // index touching it; events at or after T answer COMPLETE, the message of a position comes
 // from its last index.
 // This kernel is the serial form: lane 0 walks the chain.  It handles every long chain when the
-// parallel kernels below are off, and the barriers beyond CX_CAP when they are on.
+// parallel kernels below are off, and the barriers they could not register when they are on.
 __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work w, uint64_t now, int32_t* status) {
     __shared__ uint32_t fmin[1024];
     __shared__ uint32_t fmax[1024];
     const uint32_t lane = threadIdx.x;
     const uint32_t nc = w.counters[C_COMPLEX];
-    for (uint32_t c = blockIdx.x + (w.cx_on ? CX_CAP : 0); c < nc; c += gridDim.x) {
+    for (uint32_t c = blockIdx.x; c < nc; c += gridDim.x) {
+        if (w.cx_on && c < CX_CAP && w.cx_off[c] != IDX_NONE) continue;       // the parallel kernels have it
         const uint32_t s = w.complex_[c];
         Slot* sl = &t.slots[s];
         const uint32_t count = sl->count, slab = sl->slab;
@@ -412,78 +413,141 @@ __device__ inline uint32_t cx_lookup(const Work& w, uint32_t slab) {
     }
 }
 
-__global__ void __launch_bounds__(64) cx_init_kernel(Table t, Work w) {
+constexpr int CX_BPB = 16;      // barriers per block in cx_init
+
+// 16 barriers per block: their shares of the pool come from ONE atomic per block (a wave scan of the
+// counts), then all threads clear the shares.
+__global__ void __launch_bounds__(256) cx_init_kernel(Table t, Work w) {
+    __shared__ uint32_t s_off[CX_BPB], s_cnt[CX_BPB];
     const uint32_t nc = min(w.counters[C_COMPLEX], CX_CAP);
-    for (uint32_t c = blockIdx.x; c < nc; c += gridDim.x) {
-        const Slot* sl = &t.slots[w.complex_[c]];
-        const uint32_t count = sl->count;
-        for (uint32_t p = threadIdx.x; p < count; p += 64) {
-            w.cx_fmin[c * 1024 + p] = IDX_NONE;
-            w.cx_fmax[c * 1024 + p] = 0;
+    const uint32_t c0 = blockIdx.x * CX_BPB;
+    if (c0 >= nc) return;
+    const uint32_t tid = threadIdx.x;
+    if (tid < 64) {
+        const uint32_t c = c0 + tid;
+        const bool has = tid < CX_BPB && c < nc;
+        uint32_t count = 0, slab = 0, hot = 0;
+        if (has) {
+            const Slot* sl = &t.slots[w.complex_[c]];
+            count = sl->count;
+            slab = sl->slab;                       // unique per barrier, never 0 for a joinable barrier
+            hot = (sl->meta & META_HOT) ? 1u : 0u;
         }
-        if (threadIdx.x == 0) {
-            w.cx_atmin[c] = NQ;
-            w.cx_cnt[c] = 0;
-            const uint32_t slab = sl->slab;        // unique per barrier, never 0 for a joinable barrier
-            for (uint32_t h = cx_hash(slab);; h = (h + 1) & (CX_HASH - 1)) {
-                if (atomicCAS(&w.cx_keys[h], 0u, slab) == 0u) { w.cx_val[h] = c; break; }
+        // a barrier already known to be hot spreads its positions over one 64-byte line each: thousands
+        // of atomics on ONE line would queue up
+        const uint32_t share = hot ? count * CX_HOT_STRIDE : count;
+        const uint32_t incl = wave_incl_scan(share);
+        const uint32_t total = __shfl(incl, 63);
+        uint32_t base = 0;
+        if (tid == 63) base = atomicAdd(&w.counters[C_CXPOOL], total);
+        base = __shfl(base, 63);
+        if (tid < CX_BPB) {
+            uint32_t off = IDX_NONE;
+            if (has) {
+                off = base + incl - share;
+                if (off > CX_POOL - share) off = IDX_NONE;          // pool exhausted: left to the serial kernel
+                w.cx_off[c] = off;
+                if (off != IDX_NONE) {
+                    w.cx_atmin[c] = NQ;
+                    w.cx_cnt[c] = 0;
+                    w.cx_hot[c] = hot;
+                    for (uint32_t h = cx_hash(slab);; h = (h + 1) & (CX_HASH - 1)) {
+                        if (atomicCAS(&w.cx_keys[h], 0u, slab) == 0u) { w.cx_val[h] = c; break; }
+                    }
+                }
             }
+            s_off[tid] = off;
+            s_cnt[tid] = share;
         }
+    }
+    __syncthreads();
+    for (int j = 0; j < CX_BPB; ++j) {
+        const uint32_t off = s_off[j];
+        if (off == IDX_NONE) continue;
+        for (uint32_t p = tid; p < s_cnt[j]; p += 256) w.cx_mm[off + p] = make_uint2(IDX_NONE, 0);
     }
 }
 
 __global__ void __launch_bounds__(256) cx_scan_kernel(Work w, uint32_t n, uint64_t now) {
     if (w.counters[C_COMPLEX] == 0) return;
-    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t d = w.dst[i];
-        if (d == NODST) continue;
-        const uint32_t c = cx_lookup(w, (uint32_t)d);
-        if (c == IDX_NONE) continue;
-        const uint64_t x = w.node[i];
-        const uint32_t pos = node_pos(x), mw = node_mw(x);
-        atomicMin(&w.cx_fmin[c * 1024 + pos], (uint32_t)i);
-        atomicMax(&w.cx_fmax[c * 1024 + pos], (uint32_t)i + 1);
-        atomicAdd(&w.cx_cnt[c], 1u);
-        if (mw) atomicMin(&w.cx_atmin[c], (unsigned long long)(now + 1000ull * mw));
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave0 = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) - lane;
+    // every wave walks whole groups of 64 consecutive events (uniform trip count: the ballots below need it)
+    for (uint64_t base = wave0; base < n; base += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t i = base + lane;
+        uint32_t c = IDX_NONE, key = 0, mw = 0;
+        if (i < n) {
+            const uint64_t d = w.dst[i];
+            if (d != NODST) c = cx_lookup(w, (uint32_t)d);
+            if (c != IDX_NONE) {
+                const uint64_t x = w.node[i];
+                key = w.cx_off[c] + node_pos(x) * (w.cx_hot[c] ? CX_HOT_STRIDE : 1u);   // first and last index share 8 bytes
+                mw = node_mw(x);
+            }
+        }
+        const bool live = c != IDX_NONE;
+        const bool hot = live && w.cx_hot[c] != 0;
+        if (live && !hot) {
+            atomicMin(&w.cx_mm[key].x, (uint32_t)i);
+            atomicMax(&w.cx_mm[key].y, (uint32_t)i + 1);
+            atomicAdd(&w.cx_cnt[c], 1u);
+        }
+        // a barrier known to be hot: the lanes that hit the same position fold into one set of atomics
+        // (their indices grow with the lane, so the first lane has the smallest, the last the largest)
+        uint64_t todo = __ballot(hot);
+        while (todo) {
+            const int l0 = __ffsll((unsigned long long)todo) - 1;
+            const uint32_t key0 = __shfl(key, l0);
+            const uint64_t grp = __ballot(hot && key == key0);
+            if ((int)lane == l0) {
+                const int last = 63 - __clzll((unsigned long long)grp);
+                atomicMin(&w.cx_mm[key].x, (uint32_t)i);
+                atomicMax(&w.cx_mm[key].y, (uint32_t)(base + last) + 1);
+                // the event count only steers heuristics (stay hot? which kernels next batch?): one wave
+                // in 16 reports, scaled, instead of every wave hammering one word
+                if (((base >> 6) & 15) == 0) atomicAdd(&w.cx_cnt[c], 16u * (uint32_t)__popcll(grp));
+            }
+            todo &= ~grp;
+        }
+        if (live && mw) atomicMin(&w.cx_atmin[c], (unsigned long long)(now + 1000ull * mw));
     }
 }
 
+// one wave per barrier; 64 consecutive positions (one bitmap word) per step, read coalesced
 __global__ void __launch_bounds__(64) cx_finalize_kernel(Table t, Work w, uint64_t now) {
     const uint32_t lane = threadIdx.x;
     const uint32_t nc = min(w.counters[C_COMPLEX], CX_CAP);
+    uint32_t longest = 0;
     for (uint32_t c = blockIdx.x; c < nc; c += gridDim.x) {
+        const uint32_t off = w.cx_off[c];
+        if (off == IDX_NONE) continue;
         const uint32_t s = w.complex_[c];
         Slot* sl = &t.slots[s];
         const uint32_t count = sl->count, slab = sl->slab;
-        const uint32_t* fmin = &w.cx_fmin[c * 1024];
+        const uint64_t bits_pre = sl->bits;
+        const uint32_t pstride = w.cx_hot[c] ? CX_HOT_STRIDE : 1u;
         uint32_t t_complete = 0, n_new = 0;
+        uint64_t bits0 = bits_pre;
         const uint32_t words = (count + 63) >> 6;
-        uint64_t bits0 = sl->bits;
-        for (uint32_t wd = lane; wd < words; wd += 64) {
-            uint64_t word = count > 64 ? slab_bitmap(t, slab)[wd] : bits0;
-            uint64_t add = 0;
-            for (uint32_t b = 0; b < 64 && wd * 64 + b < count; ++b) {
-                const uint32_t p = wd * 64 + b;
-                const uint32_t f = fmin[p];
-                if (f != IDX_NONE && !((word >> b) & 1)) {
-                    add |= 1ull << b;
-                    ++n_new;
-                    if (f > t_complete) t_complete = f;
-                }
-            }
+        for (uint32_t wd = 0; wd < words; ++wd) {
+            const uint32_t p = wd * 64 + lane;
+            const uint64_t word = count > 64 ? slab_bitmap(t, slab)[wd] : bits_pre;
+            const uint32_t f = p < count ? w.cx_mm[off + p * pstride].x : IDX_NONE;
+            const bool fresh = f != IDX_NONE && !((word >> lane) & 1);
+            if (fresh && f > t_complete) t_complete = f;
+            const uint64_t add = __ballot(fresh);
+            n_new += (uint32_t)__popcll(add);          // the same in every lane
             if (add) {
-                if (count > 64) slab_bitmap(t, slab)[wd] = word | add;
+                if (count > 64) { if (lane == 0) slab_bitmap(t, slab)[wd] = word | add; }
                 else bits0 = word | add;
             }
         }
-        for (int off = 32; off > 0; off >>= 1) {
-            n_new += __shfl_xor(n_new, off);
-            uint32_t o = __shfl_xor(t_complete, off);
-            if (o > t_complete) t_complete = o;
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t v = __shfl_xor(t_complete, o);
+            if (v > t_complete) t_complete = v;
         }
-        bits0 = __shfl(bits0, 0);
         if (lane == 0) {
-            const uint32_t arrived_pre = count > 64 ? (uint32_t)sl->bits : (uint32_t)__popcll(sl->bits);
+            const uint32_t arrived_pre = count > 64 ? (uint32_t)bits_pre : (uint32_t)__popcll(bits_pre);
             const uint32_t arrived = arrived_pre + n_new;
             uint32_t T = IDX_NONE;
             if (arrived_pre == count) T = 0;
@@ -498,10 +562,12 @@ __global__ void __launch_bounds__(64) cx_finalize_kernel(Table t, Work w, uint64
             // events before T wait (store-nearest, redis.clj:269-271); from T on the barrier is queued at now
             if (T != IDX_NONE) t.q[s] = now;
             else if (pa_pre != NQ && at_min < pa_pre) t.q[s] = at_min;
-            a_max(&w.counters[C_MAXCHAIN], w.cx_cnt[c]);
-            if (w.cx_cnt[c] >= 256) sl->meta |= META_HOT; else sl->meta &= ~META_HOT;
+            const uint32_t events = w.cx_cnt[c];
+            if (events > longest) longest = events;
+            if (events >= 256) sl->meta |= META_HOT; else sl->meta &= ~META_HOT;
         }
     }
+    if (lane == 0 && longest) a_max(&w.counters[C_MAXCHAIN], longest);       // one atomic per block
 }
 
 // pass 3: messages of surviving events into the barrier's slab.  G lanes cooperate on one
@@ -534,7 +600,7 @@ __global__ void __launch_bounds__(256) join_copy_kernel(Table t, Work w, const d
                     if (T != IDX_NONE && i >= T) status[i] = DJ_JOIN_COMPLETE;
                     else if (b.z && w.cx_nq[c]) status[i] = DJ_JOIN_NEAREST_NOT_QUEUED;
                 }
-                if (w.cx_fmax[c * 1024 + b.x] != (uint32_t)i + 1) continue;      // a later event of the batch wrote this position
+                if (w.cx_mm[w.cx_off[c] + b.x * (w.cx_hot[c] ? CX_HOT_STRIDE : 1u)].y != (uint32_t)i + 1) continue;   // a later event of the batch wrote this position
             }
         }
         if (j0 == 0) slab_posmeta(t, slab, k)[b.x] = make_uint2(b.y, b.z);
@@ -580,7 +646,7 @@ __global__ void __launch_bounds__(256) join_copy_long_kernel(Table t, Work w, co
                         if (T != IDX_NONE && i >= T) status[i] = DJ_JOIN_COMPLETE;
                         else if (b.z && w.cx_nq[c]) status[i] = DJ_JOIN_NEAREST_NOT_QUEUED;
                     }
-                    if (w.cx_fmax[c * 1024 + b.x] != (uint32_t)i + 1) live = false;
+                    if (w.cx_mm[w.cx_off[c] + b.x * (w.cx_hot[c] ? CX_HOT_STRIDE : 1u)].y != (uint32_t)i + 1) live = false;
                 }
             }
         }

@@ -14,18 +14,23 @@ def main():
     import torch
     from distributed_join_amd import capi
     from distributed_join_amd.engine import Engine
-    nb, P = 1 << 20, 64
+    # usage: mixed_counts_bench.py [barriers [fixed-count [hot-path-mode]]]
+    nb, P = (int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20), 64
+    fixed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.default_rng(3)
     k = np.arange(2, 65)
     p = 1.0 / k
-    counts = rng.choice(k, size=nb, p=p / p.sum()).astype(np.int64)
+    counts = rng.choice(k, size=nb, p=p / p.sum()).astype(np.int64) if not fixed else np.full(nb, fixed, dtype=np.int64)
+    max_count = int(counts.max())
     total = int(counts.sum())
     ids = [f"m{b:x}~t" for b in range(nb)]
     fps = capi.fingerprint_many(ids)
     dev = torch.device("cuda", 0)
-    slab = 64 * 80                                  # generous: class 64 x (8 + 64) bytes
-    e = Engine(capacity_barriers=nb, arena_bytes=nb * slab // 4 + (256 << 20), max_count=64, payload_stride=P,
+    slab = (1 << (max_count - 1).bit_length()) * (8 + P) + 256
+    e = Engine(capacity_barriers=nb, arena_bytes=nb * slab + (256 << 20), max_count=max_count, payload_stride=P,
                max_batch=1 << 21)
+    if len(sys.argv) > 3:
+        e.set_hot_path(int(sys.argv[3]))
     frecs = np.zeros(nb, dtype=capi.FORK_REC)
     frecs["fp_lo"], frecs["fp_hi"], frecs["count"], frecs["deadline_ms"] = fps[:, 0], fps[:, 1], counts, 1_700_000_000_000 + 10**9
     d_f = torch.from_numpy(frecs.view(np.uint8).reshape(-1).copy()).to(dev)
@@ -60,7 +65,7 @@ def main():
                     acc.setdefault(name, []).append(ms)
         e.sync()
         assert e.stats()["live"] == 0
-    print(f"{nb} barriers, {total} events, counts Zipf(1) on [2, 64], {P} B messages; per launch (ms):")
+    print(f"{nb} barriers, {total} events, counts {'Zipf(1) on [2, 64]' if not fixed else fixed}, {P} B messages; per launch (ms):")
     for name, v in acc.items():
         print(f"  {name:14s} avg {sum(v) / len(v):.4f}  x{len(v)}  total {sum(v):.3f}")
     e.close()
