@@ -62,6 +62,29 @@ __global__ void rand_xchg_kernel(uint64_t* __restrict__ tab, uint64_t line_mask,
     if (old == 0xfffffff3u) out[0] = old;
 }
 
+// the slot line is read, the exchange goes to a dense 4-byte column indexed by the line number
+__global__ void rand_colxchg_kernel(const uint64_t* __restrict__ tab, uint32_t* __restrict__ col, uint64_t line_mask,
+                                    uint32_t n, uint64_t seed, uint64_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t line = mix(seed + i) & line_mask;
+    uint64_t v = tab[line * 8];
+    uint32_t old = atomicExch(&col[line], i);
+    if (old + v == 0xfffffff3u) out[0] = old;
+}
+
+// K independent random lines per thread (more requests in flight per wave)
+template <int K>
+__global__ void rand_rdk_kernel(const uint64_t* __restrict__ tab, uint64_t line_mask, uint32_t n, uint64_t seed,
+                                uint64_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i * K >= n) return;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc += tab[(mix(seed + i * K + k) & line_mask) * 8];
+    if (acc == 0x1234567) out[0] = acc;
+}
+
 __global__ void rand_wr64_kernel(uint4* __restrict__ tab, uint64_t line_mask, uint32_t n, uint64_t seed) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t i = t >> 2, c = t & 3;
@@ -89,8 +112,9 @@ int main() {
     float ms = time_ms([&](int) { copy_kernel<<<256 * 16, 256>>>(src, dst, n16); }, 10);
     printf("copy 1 GiB            : %.3f ms  %.0f GB/s (read+write)\n", ms, 2.0 * GiB / ms / 1e6);
 
-    const uint32_t n = 1u << 20;
-    for (size_t tab_bytes : {size_t(128) << 20, size_t(1) << 30}) {
+    uint32_t* col; CK(hipMalloc(&col, GiB / 16)); CK(hipMemset(col, 0, GiB / 16));
+    for (uint32_t n : {1u << 20, 1u << 22})
+    for (size_t tab_bytes : {size_t(8) << 20, size_t(128) << 20, size_t(1) << 30}) {
         uint64_t line_mask = tab_bytes / 64 - 1;
         uint64_t* tab = reinterpret_cast<uint64_t*>(dst);
         printf("table %4zu MiB, %u random 64-byte lines per launch\n", tab_bytes >> 20, n);
@@ -104,9 +128,15 @@ int main() {
         printf("  rand_rmw  : %7.1f us  %.1f G lines/s\n", ms * 1e3, n / ms / 1e6);
         ms = time_ms([&](int r) { rand_xchg_kernel<<<n / 256, 256>>>(tab, line_mask, n, 7777ull * r, out); }, 20);
         printf("  rand_xchg : %7.1f us  %.1f G lines/s\n", ms * 1e3, n / ms / 1e6);
+        ms = time_ms([&](int r) { rand_colxchg_kernel<<<n / 256, 256>>>(tab, col, line_mask, n, 7777ull * r, out); }, 20);
+        printf("  rand_rd + xchg on a 4-byte column : %7.1f us\n", ms * 1e3);
+        ms = time_ms([&](int r) { rand_rdk_kernel<2><<<n / 2 / 256, 256>>>(tab, line_mask, n, 7777ull * r, out); }, 20);
+        printf("  rand_rd 2 lines per thread : %7.1f us\n", ms * 1e3);
+        ms = time_ms([&](int r) { rand_rdk_kernel<4><<<n / 4 / 256, 256>>>(tab, line_mask, n, 7777ull * r, out); }, 20);
+        printf("  rand_rd 4 lines per thread : %7.1f us\n", ms * 1e3);
         ms = time_ms([&](int r) { rand_wr64_kernel<<<n * 4 / 256, 256>>>(reinterpret_cast<uint4*>(tab), line_mask, n, 7777ull * r); }, 20);
         printf("  rand_wr64 : %7.1f us  %.1f G lines/s\n", ms * 1e3, n / ms / 1e6);
     }
-    CK(hipFree(src)); CK(hipFree(dst)); CK(hipFree(out));
+    CK(hipFree(col)); CK(hipFree(src)); CK(hipFree(dst)); CK(hipFree(out));
     return 0;
 }
