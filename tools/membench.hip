@@ -62,6 +62,30 @@ __global__ void rand_xchg_kernel(uint64_t* __restrict__ tab, uint64_t line_mask,
     if (old == 0xfffffff3u) out[0] = old;
 }
 
+// read + atomic max whose result is not used (the compiler emits the non-returning form)
+__global__ void rand_amax_kernel(uint64_t* __restrict__ tab, uint64_t line_mask, uint32_t n, uint64_t seed,
+                                 uint64_t* __restrict__ out, int with_read) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t line = mix(seed + i) & line_mask;
+    uint64_t v = with_read ? tab[line * 8] : 0;
+    atomicMax(reinterpret_cast<uint32_t*>(&tab[line * 8 + 3]), i);
+    if (v == 0x1234567) out[0] = v;
+}
+
+// read + 64-bit compare-and-swap on the word read + a non-returning max on a neighbour word (fork_claim)
+__global__ void rand_cas_kernel(uint64_t* __restrict__ tab, uint64_t line_mask, uint32_t n, uint64_t seed,
+                                uint64_t* __restrict__ out, int with_max) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t line = mix(seed + i) & line_mask;
+    uint64_t v = tab[line * 8];
+    unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&tab[line * 8]), (unsigned long long)v,
+                                       (unsigned long long)v);
+    if (with_max) atomicMax(reinterpret_cast<uint32_t*>(&tab[line * 8 + 3]), i);
+    if (old == 0x1234567) out[0] = old;
+}
+
 // the slot line is read, the exchange goes to a dense 4-byte column indexed by the line number
 __global__ void rand_colxchg_kernel(const uint64_t* __restrict__ tab, uint32_t* __restrict__ col, uint64_t line_mask,
                                     uint32_t n, uint64_t seed, uint64_t* __restrict__ out) {
@@ -128,6 +152,14 @@ int main() {
         printf("  rand_rmw  : %7.1f us  %.1f G lines/s\n", ms * 1e3, n / ms / 1e6);
         ms = time_ms([&](int r) { rand_xchg_kernel<<<n / 256, 256>>>(tab, line_mask, n, 7777ull * r, out); }, 20);
         printf("  rand_xchg : %7.1f us  %.1f G lines/s\n", ms * 1e3, n / ms / 1e6);
+        ms = time_ms([&](int r) { rand_amax_kernel<<<n / 256, 256>>>(tab, line_mask, n, 7777ull * r, out, 1); }, 20);
+        printf("  rand_rd + max (no return) : %7.1f us\n", ms * 1e3);
+        ms = time_ms([&](int r) { rand_amax_kernel<<<n / 256, 256>>>(tab, line_mask, n, 7777ull * r, out, 0); }, 20);
+        printf("  max (no return) alone : %7.1f us\n", ms * 1e3);
+        ms = time_ms([&](int r) { rand_cas_kernel<<<n / 256, 256>>>(tab, line_mask, n, 7777ull * r, out, 0); }, 20);
+        printf("  rand_rd + cas : %7.1f us\n", ms * 1e3);
+        ms = time_ms([&](int r) { rand_cas_kernel<<<n / 256, 256>>>(tab, line_mask, n, 7777ull * r, out, 1); }, 20);
+        printf("  rand_rd + cas + max : %7.1f us\n", ms * 1e3);
         ms = time_ms([&](int r) { rand_colxchg_kernel<<<n / 256, 256>>>(tab, col, line_mask, n, 7777ull * r, out); }, 20);
         printf("  rand_rd + xchg on a 4-byte column : %7.1f us\n", ms * 1e3);
         ms = time_ms([&](int r) { rand_rdk_kernel<2><<<n / 2 / 256, 256>>>(tab, line_mask, n, 7777ull * r, out); }, 20);
