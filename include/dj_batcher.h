@@ -46,7 +46,9 @@ typedef struct dj_batcher_stats {
     uint64_t tasks;             /* dj_batcher_run calls executed */
 } dj_batcher_stats;
 
-/* The engine must outlive the batcher and must not be called directly while the batcher lives. */
+/* The engine must outlive the batcher.  Other threads may still call the engine directly (its entry
+ * points serialise themselves), but such a call lands between any two calls of the drain thread,
+ * e.g. between the forks and the joins of one batch; dj_batcher_run() places it between two batches. */
 int dj_batcher_create(dj_engine* e, const dj_batcher_config* cfg, dj_batcher** out);
 /* Applies what is still queued, answers it, stops the thread. */
 void dj_batcher_destroy(dj_batcher* b);
