@@ -108,6 +108,7 @@
 ;; device buffers of the publisher (one sweep / ack / recover at a time: the two scheduler threads of
 ;; ring.clj:113-114 take this lock around their poll)
 (defonce ^:private publisher-lock (Object.))
+(defonce ^:private last-sweep-rows (atom 0))       ; rows the last sweep wrote, unused (void) ones included
 (defonce ^:private buffers
   (delay (let [positions (* sweep-cap max-count)]
            {:conts    (device-alloc (* 64 sweep-cap))
@@ -213,7 +214,7 @@
 
 (defn sweep
   "One poll of the publisher (core.clj:180-188 up to the POST).  Deferred of a vector of
-  {:barrier-id :metadata :timeout? :messages [...] :index i}; :metadata is nil for an id that was
+  {:barrier-id :metadata :timeout? :messages [...] :index row}; :metadata is nil for an id that was
   queued without metadata (core.clj:159-161).  Call ack with the same vector before the next sweep."
   [now-ms]
   (deferred/future
@@ -229,7 +230,11 @@
               h-lens (to-host lens (* 4 positions))
               h-waits (to-host waits (* 4 positions))
               h-pay (to-host payloads (* payload-stride positions))]
-          (mapv (fn [i]
+          (reset! last-sweep-rows n)
+          (into []
+                (comp
+                 (remove (fn [i] (neg? (.getInt h-conts (+ (* 64 i) 36)))))   ; DJ_CONT_VOID (bit 31): row not used
+                 (map (fn [i]
                   (let [o (* 64 i)
                         fp [(.getLong h-conts o) (.getLong h-conts (+ o 8))]
                         flags (.getInt h-conts (+ o 36))
@@ -241,7 +246,7 @@
                      :timeout? (pos? (bit-and 1 flags))                ; DJ_CONT_TIMEOUT, core.clj:86-89
                      :messages (mapv :message (read-messages id h-lens h-waits h-pay
                                                              (.getLong h-conts (+ o 48)) (.getInt h-conts (+ o 32))))
-                     :fingerprint fp}))
+                     :fingerprint fp}))))
                 (range n)))))))
 
 (def ^:private ack-status
@@ -254,20 +259,21 @@
   (deferred/future
     (locking publisher-lock
       (let [{:keys [conts ok status]} @buffers
-            n (count continuations)
+            n @last-sweep-rows
             h-ok (Memory. (max n 1))]
-        (doseq [[i p] (map-indexed vector published?)]
-          (.setByte h-ok i (byte (if p 1 0))))
+        (.clear h-ok)
+        (doseq [[c p] (map vector continuations published?)]
+          (.setByte h-ok (:index c) (byte (if p 1 0))))
         (to-device ok h-ok n)
         (check (native-int dj "dj_ack_batch" @engine (int n) Pointer/NULL conts ok (long now-ms) status) "dj_ack_batch")
         (check (native-int dj "dj_sync" @engine) "dj_sync")
         (let [h-status (to-host status (* 4 n))]
-          (mapv (fn [c i]
-                  (let [s (ack-status (.getInt h-status (* 4 i)))]
+          (mapv (fn [c]
+                  (let [s (ack-status (.getInt h-status (* 4 (:index c))))]
                     (when (#{:done :dropped-exhausted :done-no-metadata} s)
                       (.remove forks (:fingerprint c)))
                     s))
-                continuations (range n)))))))
+                continuations))))))
 
 (defn recover
   "core/recover-unprocessed-publish-messages (core.clj:193-201).  Deferred of [barrier-id outcome] pairs."

@@ -23,7 +23,7 @@ DJ_FORK_CREATED, DJ_FORK_TABLE_FULL, DJ_FORK_NO_SPACE, DJ_FORK_BAD_COUNT = 1, 2,
 DJ_ACK_DONE, DJ_ACK_REQUEUED_DIRTY, DJ_ACK_RETRY = 1, 2, 3
 DJ_ACK_DROPPED_EXHAUSTED, DJ_ACK_DONE_NO_METADATA = 4, 5
 DJ_CONT_TIMEOUT, DJ_CONT_NO_METADATA = 1, 2
-CONT_VOID = 0x80000000
+DJ_CONT_VOID = CONT_VOID = 0x80000000
 
 # ---- record layouts (little-endian, no padding surprises: all fields naturally aligned)
 FORK_REC = np.dtype([("fp_lo", "<u8"), ("fp_hi", "<u8"), ("count", "<u4"), ("reserved", "<u4"),

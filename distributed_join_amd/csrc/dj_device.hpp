@@ -41,7 +41,7 @@ constexpr int OVF_CLASSES = 15;        // blocks for long messages: 1 << k units
 constexpr uint32_t RETRY_NIL = 0xFFu;  // retry counter absent
 constexpr int NUM_CLASSES = 11;        // 1, 2, 4 ... 1024 positions
 constexpr uint64_t NODST = ~0ull;
-constexpr uint32_t CONT_VOID = 0x80000000u;  // internal: descriptor index allocated but not popped
+constexpr uint32_t CONT_VOID = DJ_CONT_VOID;  // descriptor index allocated but not popped
 
 struct __attribute__((aligned(64))) Slot {
     uint64_t fp_lo, fp_hi;

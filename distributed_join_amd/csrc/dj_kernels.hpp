@@ -827,8 +827,9 @@ __global__ void __launch_bounds__(256) pop_due_kernel(Table t, Work w, uint64_t 
                     w.sweep[S_MORE] = 1;
                 } else if (alloc_pos && p_idx + cnt > cap_pos) {
                     w.sweep[S_MORE] = 1;
-                    conts[c_idx].flags = CONT_VOID;      // index taken, barrier stays queued
-                    conts[c_idx].count = 0;
+                    dj_cont v = {};                      // index taken, barrier stays queued
+                    v.flags = CONT_VOID;
+                    conts[c_idx] = v;
                     w.cont_slot[c_idx] = 0xFFFFFFFFu;
                 } else {
                     t.q[s] = pa | Q_POPPED;              // popped; the backup entry stays (redis.clj:288)

@@ -118,6 +118,9 @@ typedef struct dj_join_rec {
 
 #define DJ_CONT_TIMEOUT      1u /* now > :timeout-secs, strict (core.clj:86-89): goes to :timeout-destination */
 #define DJ_CONT_NO_METADATA  2u /* id was queued but has no metadata (core.clj:159-161) */
+#define DJ_CONT_VOID 0x80000000u /* unused output row: the barrier's positions did not fit under cap_positions, so it
+                                    stays queued (dj_sweep_result.more is set).  Every other field of the row is 0.
+                                    Readers skip it; dj_ack_batch answers it with status 0 */
 
 /* one popped barrier = one continuation to publish: 64 bytes.  It doubles as the
  * metadata snapshot that core/publish-message holds while it publishes
@@ -196,7 +199,8 @@ int dj_pop_due(dj_engine* e, uint64_t now_ms, uint32_t cap_conts,
  * Position p of continuation k: d_lens[pos_base+p] = message length or DJ_NIL when the
  * position is missing; d_max_waits[...] = its :max-wait (0 absent; may be NULL);
  * bytes at d_payloads + (pos_base+p) * payload_stride.  A barrier is popped only if its
- * count still fits under cap_positions.  h_result (optional) makes the call synchronous. */
+ * count still fits under cap_positions; one that does not may leave a DJ_CONT_VOID row among the
+ * n_conts rows written.  h_result (optional) makes the call synchronous. */
 int dj_sweep(dj_engine* e, uint64_t now_ms, uint32_t cap_conts, uint64_t cap_positions,
              dj_cont* d_conts, uint32_t* d_lens, uint32_t* d_max_waits, uint8_t* d_payloads,
              dj_sweep_result* d_result, dj_sweep_result* h_result);

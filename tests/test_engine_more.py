@@ -446,3 +446,166 @@ def test_config4_one_rank_share_scaled():
         assert s["live"] == 0 and s["tombstones"] == nb
     finally:
         e.close()
+
+
+def _splitmix64_t(torch, x):
+    """tests.parity.splitmix64 on int64 tensors (two's-complement wrap-around, logical shifts)."""
+    def shr(v, k):
+        return (v >> k) & ((1 << (64 - k)) - 1)
+    x = x + (-7046029254386353131)               # 0x9E3779B97F4A7C15
+    x = (x ^ shr(x, 30)) * (-4658895280553007687)  # 0xBF58476D1CE4E5B9
+    x = (x ^ shr(x, 27)) * (-7723592293110705685)  # 0x94D049BB133111EB
+    return x ^ shr(x, 31)
+
+
+def _payload_bytes_t(torch, barrier, pos, pitch):
+    """tests.parity.payload_bytes (version 0) on the device -> uint8 (n, pitch)."""
+    base = _splitmix64_t(torch, barrier * 1024 + pos)
+    k = torch.arange(pitch // 8, dtype=torch.int64, device=barrier.device) * 0x100000001B3
+    return _splitmix64_t(torch, base[:, None] + k[None, :]).view(torch.uint8).reshape(len(barrier), pitch)
+
+
+def test_config3_full_size_properties():
+    """BASELINE config #3 at full size: 10 M barriers, counts Zipf(1) over [2, 64], 30 % of the barriers get a
+    strict subset of their positions and a deadline inside the run, the clock advances per batch.  Checked
+    without the oracle, from what the generator knows: every barrier fires exactly once; the 70 % fire COMPLETE
+    and the 30 % TIMEOUT; a continuation holds exactly the positions that were sent before its deadline, each
+    with the generator's bytes; joins that arrive after their barrier fired are answered NOT_FOUND."""
+    import time
+    import torch
+    t_start = time.time()
+    nb, P, batch = 10_000_000, 64, 1 << 22
+    rng = np.random.default_rng(3)
+    ids = [f"j{b:x}~t{b:x}" for b in range(nb)]
+    fps_np = capi.fingerprint_many(ids).view(np.int64)
+    del ids
+    counts_np = zipf_counts(rng, nb)
+    e = _engine(capacity_barriers=nb, arena_bytes=26 << 30, max_count=64, payload_stride=P, max_batch=nb)
+    dev = e.device
+    NIL = 0xFFFFFFFF
+    try:
+        assert np.array_equal(_payload_bytes_t(torch, torch.arange(5, device=dev), torch.arange(5, device=dev) * 3, P).cpu().numpy(),
+                              payload_bytes(np.arange(5), np.arange(5) * 3, np.zeros(5), P))
+        g = torch.Generator(device=dev)
+        g.manual_seed(3)
+        fps = torch.from_numpy(fps_np).to(dev)
+        counts = torch.from_numpy(counts_np).to(dev)
+        offsets = torch.cumsum(counts, 0) - counts                     # first (barrier, position) cell of each barrier
+        cells = int(counts.sum())
+        expire = torch.rand(nb, device=dev, generator=g) < 0.3
+        # (barrier, position) cells; an expiring barrier never gets position hash(b) % count, the others with p = 1/2
+        cell_b = torch.repeat_interleave(torch.arange(nb, device=dev), counts)
+        cell_p = torch.arange(cells, device=dev) - offsets[cell_b]
+        h = _splitmix64_t(torch, cell_b * 64 + cell_p + (1 << 50))
+        never = (_splitmix64_t(torch, cell_b + (1 << 51)) & 0xFFFF) % counts[cell_b]
+        sent = ~expire[cell_b] | ((cell_p != never) & ((h & 1) == 1))
+        del h, never
+        ev_cell = torch.nonzero(sent).reshape(-1)
+        ev_cell = ev_cell[torch.randperm(len(ev_cell), device=dev, generator=g)]
+        n_events = len(ev_cell)
+        n_batches = (n_events + batch - 1) // batch
+        t_of = lambda k: T0 + 2 * (k + 1)                              # joins and sweep of batch k; even milliseconds
+        # deadlines on odd milliseconds: popped at the first sweep after them, strictly late (core.clj:86-89)
+        deadline = torch.where(expire, T0 + 11 + 2 * torch.randint(0, n_batches, (nb,), device=dev, generator=g),
+                               torch.full((nb,), T0 + 3_600_000, device=dev))
+        # expected presence of every cell: sent, and applied before the sweep that pops the barrier (the first
+        # one at or after the deadline, i.e. at deadline + 1; a batch's joins run before its sweep)
+        arrive = torch.full((cells,), 1 << 60, dtype=torch.int64, device=dev)
+        arrive[ev_cell] = T0 + 2 * (torch.arange(n_events, device=dev) // batch + 1)
+        present = arrive <= deadline[cell_b] + 1
+        late_events = int((sent & ~present).sum())
+        del arrive, sent
+
+        frecs = torch.empty((nb, 4), dtype=torch.int64, device=dev)
+        frecs[:, 0], frecs[:, 1], frecs[:, 2], frecs[:, 3] = fps[:, 0], fps[:, 1], counts, deadline
+        d_status = torch.empty(nb, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        e.fork_batch_dev(nb, frecs, d_status)
+        e.sync()
+        assert bool((d_status == capi.DJ_FORK_CREATED).all())
+        del frecs
+
+        order = torch.argsort(fps[:, 0])
+        sorted_lo = fps[order, 0].contiguous()
+        cap_c, cap_p = 1 << 21, 40_000_000
+        d_conts = torch.empty((cap_c, 8), dtype=torch.int64, device=dev)
+        d_lens = torch.empty(cap_p, dtype=torch.int32, device=dev)
+        d_pay = torch.empty((cap_p, P), dtype=torch.uint8, device=dev)
+        d_res = torch.empty(16, dtype=torch.uint8, device=dev)
+        d_ack = torch.empty(cap_c, dtype=torch.int32, device=dev)
+        fired = torch.zeros(nb, dtype=torch.int32, device=dev)
+        n_complete = n_timeout = n_not_found = n_status_complete = 0
+        print(f"\n  generated {n_events} events over {nb} barriers in {time.time() - t_start:.1f} s", flush=True)
+
+        def sweep_and_check(now):
+            nonlocal n_complete, n_timeout
+            while True:
+                res = np.zeros(1, dtype=capi.SWEEP_RESULT)
+                e.sweep_dev(now, cap_c, cap_p, d_conts, d_lens, None, d_pay, d_res, res)
+                n, npos = int(res[0]["n_conts"]), int(res[0]["n_positions"])
+                if n:
+                    c = d_conts[:n]
+                    # rows of barriers that did not fit under cap_positions are void; they stay queued
+                    void = ((c[:, 4] >> 32) & capi.DJ_CONT_VOID) != 0
+                    assert bool(void.any()) <= bool(res[0]["more"])
+                    c = c[~void].contiguous()
+                    rows_acked = n
+                    n = len(c)
+                if n:
+                    at = torch.searchsorted(sorted_lo, c[:, 0].contiguous()).clamp_(max=nb - 1)
+                    b = order[at]
+                    assert bool((fps[b, 0] == c[:, 0]).all()) and bool((fps[b, 1] == c[:, 1]).all())
+                    fired.index_add_(0, b, torch.ones(n, dtype=torch.int32, device=dev))
+                    cnt = c[:, 4] & 0xFFFFFFFF
+                    flags = c[:, 4] >> 32
+                    assert bool((cnt == counts[b]).all())
+                    assert bool(((flags & capi.DJ_CONT_TIMEOUT) != 0).eq(expire[b]).all())
+                    assert bool((c[:, 2] == deadline[b]).all())
+                    tot = int(cnt.sum())
+                    assert tot <= npos and (tot == npos or bool(void.any()))
+                    n_timeout += int(expire[b].sum())
+                    n_complete += n - int(expire[b].sum())
+                    # positions of the continuations -> their cells
+                    k_of = torch.repeat_interleave(torch.arange(n, device=dev), cnt)
+                    p_of = torch.arange(tot, device=dev) - (torch.cumsum(cnt, 0) - cnt)[k_of]
+                    row = c[k_of, 6] + p_of                             # pos_base + position
+                    cell = offsets[b][k_of] + p_of
+                    want_len = torch.where(present[cell], P, NIL - (1 << 32)).to(torch.int32)
+                    assert bool((d_lens[row] == want_len).all()), "presence differs from what was sent in time"
+                    here = present[cell]
+                    want = _payload_bytes_t(torch, b[k_of][here], p_of[here], P)
+                    assert bool((d_pay[row[here]] == want).all()), "a gathered byte differs from the generator"
+                    torch.cuda.synchronize()
+                    e.ack_batch_dev(rows_acked, None, d_conts, None, now, d_ack)
+                    e.sync()
+                    assert bool((d_ack[:rows_acked][~void] == capi.DJ_ACK_DONE).all()) and bool((d_ack[:rows_acked][void] == 0).all())
+                if not res[0]["more"]:
+                    return
+
+        d_jst = torch.empty(batch, dtype=torch.int32, device=dev)
+        for k in range(n_batches):
+            now = t_of(k)
+            cell = ev_cell[k * batch:(k + 1) * batch]
+            n = len(cell)
+            jb, jp = cell_b[cell], cell_p[cell]
+            recs = torch.empty((n, 4), dtype=torch.int64, device=dev)
+            recs[:, 0], recs[:, 1], recs[:, 2], recs[:, 3] = fps[jb, 0], fps[jb, 1], jp | (P << 32), 0
+            pay = _payload_bytes_t(torch, jb, jp, P)
+            torch.cuda.synchronize()
+            e.join_batch_dev(n, recs, pay, P, now, d_jst)
+            e.sync()
+            st = d_jst[:n]
+            n_not_found += int((st == capi.DJ_JOIN_NOT_FOUND).sum())
+            n_status_complete += int((st == capi.DJ_JOIN_COMPLETE).sum())
+            assert bool(((st == capi.DJ_JOIN_WAITING) | (st == capi.DJ_JOIN_COMPLETE) | (st == capi.DJ_JOIN_NOT_FOUND)).all())
+            sweep_and_check(now)
+        for k in range(n_batches, n_batches + 8):                     # the deadlines after the last batch
+            sweep_and_check(t_of(k))
+        print(f"  {n_batches} batches, {n_complete} complete + {n_timeout} timeout, {time.time() - t_start:.1f} s", flush=True)
+        assert bool((fired == 1).all())
+        assert n_complete == nb - int(expire.sum()) and n_timeout == int(expire.sum())
+        assert n_status_complete == n_complete          # one join completes each barrier that is not starved
+        assert n_not_found == late_events
+        assert e.stats()["live"] == 0
+    finally:
+        e.close()
