@@ -37,6 +37,10 @@ constexpr uint64_t Q_POPPED = 1ull << 63;   // removed from the primary queue, s
 constexpr uint32_t META_HAS = 1u;      // metadata key exists
 constexpr uint32_t META_HOT = 2u;      // hint: the barrier received hundreds of events in its last batch
 constexpr uint32_t META_OVF = 4u;      // some position of the barrier holds (or held) a long message in a block of its own
+constexpr uint32_t META_PMD = 8u;      // some position holds (or held) a message that does not fill its row exactly, or a
+                                       // max-wait: the per-position {len, max_wait} words are authoritative.  Without the
+                                       // flag every present position is {payload_stride, 0}; the words (pre-filled with
+                                       // that value at fork) are then neither written by joins nor read by gathers
 constexpr int OVF_CLASSES = 15;        // blocks for long messages: 1 << k units, 64 B .. 1 MiB
 constexpr uint32_t RETRY_NIL = 0xFFu;  // retry counter absent
 constexpr int NUM_CLASSES = 11;        // 1, 2, 4 ... 1024 positions
@@ -581,10 +585,14 @@ __device__ inline void wave_release_long_each(const Table& t, bool mine, uint32_
     }
 }
 
-// A slab that starts a new life (fork): no position holds a long message.
-__device__ inline void zero_posmeta(const Table& t, uint32_t slab, uint32_t k) {
-    uint2* pm = slab_posmeta(t, slab, k);
-    for (uint32_t p = 0; p < class_positions(k); ++p) pm[p] = make_uint2(0, 0);
+// A slab that starts a new life (fork): every position's {len, max_wait} word holds the value that
+// needs no write later, a full row without max-wait (so no position holds a long message either).
+// The area is a multiple of 64 bytes.
+__device__ inline void fill_posmeta_default(const Table& t, uint32_t slab, uint32_t k) {
+    uint4* pm = reinterpret_cast<uint4*>(slab_posmeta(t, slab, k));
+    const uint32_t n16 = (slab_payload_off(k) - slab_posmeta_off(k)) >> 4;
+    const uint4 v = make_uint4(t.stride, 0, t.stride, 0);
+    for (uint32_t j = 0; j < n16; ++j) pm[j] = v;
 }
 
 // node packing of the join link pass: next (25) | position (10) | max-wait (29)
@@ -596,6 +604,9 @@ __device__ inline uint32_t node_next(uint64_t x) { return (uint32_t)(x & 0x1FFFF
 __device__ inline uint32_t node_pos(uint64_t x) { return (uint32_t)((x >> 25) & 0x3FFu); }
 __device__ inline uint32_t node_mw(uint64_t x) { return (uint32_t)(x >> 35); }
 
+// where an event's message goes: slab (32) | count (10) ... | DST_PM: also write the position's {len, max_wait}
+constexpr uint64_t DST_PM = 1ull << 62;
 __device__ inline uint64_t dst_pack(uint32_t slab, uint32_t count) { return (uint64_t)slab | ((uint64_t)count << 32); }
+__device__ inline uint32_t dst_count(uint64_t d) { return (uint32_t)(d >> 32) & 0xFFFFu; }
 
 }  // namespace dj

@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(FORK_APPLY_BLOCK) fork_apply_kernel(Table t, W
         uint64_t* bm = slab_bitmap(t, slab);
         for (uint32_t j = 0; j < (class_positions(k_new) >> 6); ++j) bm[j] = 0;
     }
-    if (long_on) zero_posmeta(t, slab, k_new);             // no position holds a long message
+    fill_posmeta_default(t, slab, k_new);                 // and no position holds a long message
     sl->count = r.count;                                  // SET <id>:metadata
     sl->meta = meta_pack(true, RETRY_NIL, RETRY_NIL);
     sl->slab = slab;
@@ -157,7 +157,11 @@ join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t 
             // the common answers are written here, coalesced; the resolve pass only overwrites the
             // exceptions (COMPLETE / NEAREST_NOT_QUEUED statuses, superseded messages)
             status[i] = DJ_JOIN_WAITING;
-            w.dst[i] = dst_pack(info.z, info.x);
+            // {len, max_wait} of a position is stored only when it differs from a full row without max-wait,
+            // or when the barrier has seen such a position before (META_PMD, sticky until the next fork)
+            const bool pm = (info.y & META_PMD) || b.y != t.stride || b.z != 0;
+            w.dst[i] = dst_pack(info.z, info.x) | (pm ? DST_PM : 0ull);
+            if (pm && !(info.y & META_PMD)) atomicOr(&t.slots[s].meta, META_PMD);
             slot = (uint32_t)s;
             w.ev_slot[i] = slot;
             if (HOT && (info.y & META_HOT)) {
@@ -590,7 +594,7 @@ __global__ void __launch_bounds__(256) join_copy_kernel(Table t, Work w, const d
         const uint64_t d = w.dst[i];
         if (d == NODST) continue;
         const uint4 b = reinterpret_cast<const uint4*>(recs)[2 * i + 1];   // position, len, max_wait
-        const uint32_t slab = (uint32_t)d, k = class_of((uint32_t)(d >> 32));
+        const uint32_t slab = (uint32_t)d, k = class_of(dst_count(d));
         if (hot) {
             // an event of a hot barrier gets its answer here, from the tables of the cx_* kernels
             const uint32_t c = cx_lookup(w, slab);
@@ -603,7 +607,7 @@ __global__ void __launch_bounds__(256) join_copy_kernel(Table t, Work w, const d
                 if (w.cx_mm[w.cx_off[c] + b.x * (w.cx_hot[c] ? CX_HOT_STRIDE : 1u)].y != (uint32_t)i + 1) continue;   // a later event of the batch wrote this position
             }
         }
-        if (j0 == 0) slab_posmeta(t, slab, k)[b.x] = make_uint2(b.y, b.z);
+        if (j0 == 0 && (d & DST_PM)) slab_posmeta(t, slab, k)[b.x] = make_uint2(b.y, b.z);
         const uint4* src = reinterpret_cast<const uint4*>(payloads + i * pitch);
         uint4* dstp = reinterpret_cast<uint4*>(slab_payload(t, slab, k) + (uint64_t)b.x * t.stride);
         const uint32_t chunks = (b.y + 15) >> 4;
@@ -635,7 +639,7 @@ __global__ void __launch_bounds__(256) join_copy_long_kernel(Table t, Work w, co
             d = w.dst[i];
             live = d != NODST;
         }
-        const uint32_t slab = (uint32_t)d, k = live ? class_of((uint32_t)(d >> 32)) : 0;
+        const uint32_t slab = (uint32_t)d, k = live ? class_of(dst_count(d)) : 0;
         if (live) {
             b = reinterpret_cast<const uint4*>(recs)[2 * i + 1];   // position, len, max_wait
             if (hot) {
@@ -884,6 +888,7 @@ __global__ void __launch_bounds__(256) gather_kernel(Table t, Work w, const dj_c
         const uint64_t pos_base = conts[kc].pos_base;
         Slot* sl = &t.slots[s];
         const uint32_t count = head.x, slab = sl->slab, k = class_of(count);
+        const bool stored_meta = (sl->meta & META_PMD) != 0;    // else every present position is a full row, no max-wait
         const uint64_t bits0 = sl->bits;
         if (update_ts && j == 0) sl->join_ts_read = sl->join_ts;
         const uint64_t* bm = slab_bitmap(t, slab);
@@ -891,7 +896,7 @@ __global__ void __launch_bounds__(256) gather_kernel(Table t, Work w, const dj_c
         const uint8_t* pay = slab_payload(t, slab, k);
         for (uint32_t p = j; p < count; p += GS) {
             const bool present = count > 64 ? ((bm[p >> 6] >> (p & 63)) & 1) : ((bits0 >> p) & 1);
-            const uint2 meta = present ? pm[p] : make_uint2(DJ_NIL, 0);
+            const uint2 meta = !present ? make_uint2(DJ_NIL, 0) : stored_meta ? pm[p] : make_uint2(t.stride, 0);
             if (lens) lens[pos_base + p] = meta.x;
             if (max_waits) max_waits[pos_base + p] = meta.y;
         }
@@ -902,7 +907,7 @@ __global__ void __launch_bounds__(256) gather_kernel(Table t, Work w, const dj_c
             const uint32_t p = it / CH, ch = it - p * CH;
             const bool present = count > 64 ? ((bm[p >> 6] >> (p & 63)) & 1) : ((bits0 >> p) & 1);
             if (!present) continue;
-            const uint32_t len = pm[p].x;       // a long message leaves its 16-byte reference in the row
+            const uint32_t len = stored_meta ? pm[p].x : t.stride;   // a long message leaves its 16-byte reference in the row
             if (ch >= (len > t.stride ? 1u : ((len + 15) >> 4))) continue;
             nt_store(&reinterpret_cast<uint4*>(payloads + (pos_base + p) * (uint64_t)t.stride)[ch],
                      nt_load(&reinterpret_cast<const uint4*>(pay + (uint64_t)p * t.stride)[ch]));
@@ -923,7 +928,7 @@ __device__ inline bool complete_decide(const Table& t, uint64_t s, uint64_t now)
     Slot* sl = &t.slots[s];
     if (sl->join_ts == sl->join_ts_read) return true;          // two nils compare equal
     // reset-publish: both retry counters dropped, :publish-retry-cnt 0, re-queued at now
-    sl->meta = meta_pack(sl->meta & META_HAS, 0, RETRY_NIL) | (sl->meta & META_OVF);
+    sl->meta = meta_pack(sl->meta & META_HAS, 0, RETRY_NIL) | (sl->meta & (META_OVF | META_PMD));
     t.q[s] = now;
     return false;
 }
@@ -941,7 +946,7 @@ __device__ inline bool retries_left(const Table& t, uint64_t deadline, uint32_t 
 __device__ inline void retry_requeue(const Table& t, uint64_t s, bool timeout, uint32_t cnt, uint32_t rp, uint32_t rt,
                                      uint64_t now) {
     if (timeout) rt = cnt + 1; else rp = cnt + 1;
-    t.slots[s].meta = meta_pack(true, rp, rt) | (t.slots[s].meta & META_OVF);
+    t.slots[s].meta = meta_pack(true, rp, rt) | (t.slots[s].meta & (META_OVF | META_PMD));
     t.q[s] = now;
 }
 
@@ -1045,7 +1050,7 @@ __global__ void __launch_bounds__(ACK_BLOCK) ack_kernel(Table t, uint32_t n_max,
         if (alloc) {
             sl->slab = fresh;
             sl->bits = 0;
-            if (long_on && fresh) zero_posmeta(t, fresh, k_new);
+            if (fresh) fill_posmeta_default(t, fresh, k_new);
             if (c.count > 64 && fresh) {
                 uint64_t* bm = slab_bitmap(t, fresh);
                 for (uint32_t j = 0; j < (class_positions(k_new) >> 6); ++j) bm[j] = 0;
