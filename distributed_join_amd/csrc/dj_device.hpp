@@ -604,9 +604,14 @@ __device__ inline uint32_t node_next(uint64_t x) { return (uint32_t)(x & 0x1FFFF
 __device__ inline uint32_t node_pos(uint64_t x) { return (uint32_t)((x >> 25) & 0x3FFu); }
 __device__ inline uint32_t node_mw(uint64_t x) { return (uint32_t)(x >> 35); }
 
-// where an event's message goes: slab (32) | count (10) ... | DST_PM: also write the position's {len, max_wait}
-constexpr uint64_t DST_PM = 1ull << 62;
-__device__ inline uint64_t dst_pack(uint32_t slab, uint32_t count) { return (uint64_t)slab | ((uint64_t)count << 32); }
-__device__ inline uint32_t dst_count(uint64_t d) { return (uint32_t)(d >> 32) & 0xFFFFu; }
+// where an event's message goes: slab (32) | size class (4) | position (10) | flags.  With DST_FULL and without
+// DST_PM the copy pass needs nothing else from the event's record.
+constexpr uint64_t DST_FULL = 1ull << 46;   // the message fills its row exactly
+constexpr uint64_t DST_PM = 1ull << 62;     // also write the position's {len, max_wait}
+__device__ inline uint64_t dst_pack(uint32_t slab, uint32_t count, uint32_t pos) {
+    return (uint64_t)slab | ((uint64_t)class_of(count) << 32) | ((uint64_t)pos << 36);
+}
+__device__ inline uint32_t dst_class(uint64_t d) { return (uint32_t)(d >> 32) & 15u; }
+__device__ inline uint32_t dst_pos(uint64_t d) { return (uint32_t)(d >> 36) & 0x3FFu; }
 
 }  // namespace dj

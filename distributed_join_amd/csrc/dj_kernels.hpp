@@ -160,7 +160,7 @@ join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t 
             // {len, max_wait} of a position is stored only when it differs from a full row without max-wait,
             // or when the barrier has seen such a position before (META_PMD, sticky until the next fork)
             const bool pm = (info.y & META_PMD) || b.y != t.stride || b.z != 0;
-            w.dst[i] = dst_pack(info.z, info.x) | (pm ? DST_PM : 0ull);
+            w.dst[i] = dst_pack(info.z, info.x, b.x) | (pm ? DST_PM : 0ull) | (b.y == t.stride ? DST_FULL : 0ull);
             if (pm && !(info.y & META_PMD)) atomicOr(&t.slots[s].meta, META_PMD);
             slot = (uint32_t)s;
             w.ev_slot[i] = slot;
@@ -593,8 +593,10 @@ __global__ void __launch_bounds__(256) join_copy_kernel(Table t, Work w, const d
         if (i >= n) continue;
         const uint64_t d = w.dst[i];
         if (d == NODST) continue;
-        const uint4 b = reinterpret_cast<const uint4*>(recs)[2 * i + 1];   // position, len, max_wait
-        const uint32_t slab = (uint32_t)d, k = class_of(dst_count(d));
+        const uint32_t slab = (uint32_t)d, k = dst_class(d);
+        // position and "full row" travel in d; the record is read only when more is needed
+        uint4 b = make_uint4(dst_pos(d), t.stride, 0, 0);                    // position, len, max_wait
+        if (hot || (d & DST_PM) || !(d & DST_FULL)) b = reinterpret_cast<const uint4*>(recs)[2 * i + 1];
         if (hot) {
             // an event of a hot barrier gets its answer here, from the tables of the cx_* kernels
             const uint32_t c = cx_lookup(w, slab);
@@ -639,7 +641,7 @@ __global__ void __launch_bounds__(256) join_copy_long_kernel(Table t, Work w, co
             d = w.dst[i];
             live = d != NODST;
         }
-        const uint32_t slab = (uint32_t)d, k = live ? class_of(dst_count(d)) : 0;
+        const uint32_t slab = (uint32_t)d, k = live ? dst_class(d) : 0;
         if (live) {
             b = reinterpret_cast<const uint4*>(recs)[2 * i + 1];   // position, len, max_wait
             if (hot) {
