@@ -117,6 +117,29 @@ __global__ void rand_wr64_kernel(uint4* __restrict__ tab, uint64_t line_mask, ui
     tab[line * 4 + c] = make_uint4(i, c, i, c);
 }
 
+// what join_copy does at P = 64: row i of a contiguous source goes to a random table line, 4 lanes x 16 bytes;
+// idx != nullptr: the destination line comes from an 8-byte word per row (as from the dst array)
+template <bool NT>
+__global__ void scatter_rows_kernel(const uint4* __restrict__ src, uint4* __restrict__ tab, const uint64_t* __restrict__ idx,
+                                    uint64_t line_mask, uint32_t n, uint64_t seed) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = t >> 2, c = t & 3;
+    if (i >= n) return;
+    uint64_t line = idx ? (idx[i] & line_mask) : (mix(seed + i) & line_mask);
+    if (NT) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(&src[(size_t)i * 4 + c]));
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(&tab[line * 4 + c]));
+    } else {
+        tab[line * 4 + c] = src[(size_t)i * 4 + c];
+    }
+}
+
+__global__ void fill_idx_kernel(uint64_t* idx, uint32_t n, uint64_t seed) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) idx[i] = mix(seed + i);
+}
+
 template <class F> static float time_ms(F f, int reps) {
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     f(0); CK(hipDeviceSynchronize());
@@ -166,6 +189,20 @@ int main() {
         printf("  rand_rd 2 lines per thread : %7.1f us\n", ms * 1e3);
         ms = time_ms([&](int r) { rand_rdk_kernel<4><<<n / 4 / 256, 256>>>(tab, line_mask, n, 7777ull * r, out); }, 20);
         printf("  rand_rd 4 lines per thread : %7.1f us\n", ms * 1e3);
+        {
+            uint64_t* idx = reinterpret_cast<uint64_t*>(col);
+            fill_idx_kernel<<<n / 256, 256>>>(idx, n, 99);
+            const uint4* rows = src;
+            uint4* t4 = reinterpret_cast<uint4*>(tab);
+            ms = time_ms([&](int r) { scatter_rows_kernel<false><<<n * 4 / 256, 256>>>(rows, t4, nullptr, line_mask, n, 7777ull * r); }, 20);
+            printf("  rows -> random lines              : %7.1f us\n", ms * 1e3);
+            ms = time_ms([&](int r) { scatter_rows_kernel<true><<<n * 4 / 256, 256>>>(rows, t4, nullptr, line_mask, n, 7777ull * r); }, 20);
+            printf("  rows -> random lines, non-temporal: %7.1f us\n", ms * 1e3);
+            ms = time_ms([&](int r) { scatter_rows_kernel<false><<<n * 4 / 256, 256>>>(rows, t4, idx, line_mask, n, 0); }, 20);
+            printf("  rows -> lines from an index array : %7.1f us\n", ms * 1e3);
+            ms = time_ms([&](int r) { scatter_rows_kernel<true><<<n * 4 / 256, 256>>>(rows, t4, idx, line_mask, n, 0); }, 20);
+            printf("  same, non-temporal                : %7.1f us\n", ms * 1e3);
+        }
         ms = time_ms([&](int r) { rand_wr64_kernel<<<n * 4 / 256, 256>>>(reinterpret_cast<uint4*>(tab), line_mask, n, 7777ull * r); }, 20);
         printf("  rand_wr64 : %7.1f us  %.1f G lines/s\n", ms * 1e3, n / ms / 1e6);
     }
