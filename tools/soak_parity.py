@@ -1,0 +1,48 @@
+"""Longer randomized parity runs than the test suite holds: engine (through the C ABI) against the CPU oracle
+on seeded op-logs with thousands of barriers and batches of tens of thousands of events, in every
+configuration the suite covers (short and long chains, multi-word bitmaps, variable lengths, messages longer
+than a row, both long-chain kernel modes).  Any difference raises.  usage: soak_parity.py [seeds [scale]]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle_py  # noqa: E402
+from tests.test_engine_parity import make_pair, run_oplog  # noqa: E402
+
+
+def main():
+    seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    scale = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    oracle_py.build()
+    cases = [
+        # name, barriers, count range, stride, rounds, batch, extra run_oplog arguments, engine arguments
+        ("small counts", 4000 * scale, (1, 9), 64, 20, 30000 * scale, dict(unknown=50), dict()),
+        ("hot barrier", 2000 * scale, (2, 65), 64, 15, 40000 * scale, dict(hot=7), dict()),
+        ("hot barrier, parallel kernels", 2000 * scale, (2, 65), 64, 15, 40000 * scale, dict(hot=7), dict(hot_mode=1)),
+        ("large counts", 300 * scale, (60, 1000), 64, 10, 60000 * scale, dict(hot=11), dict()),
+        ("large counts, parallel kernels", 300 * scale, (60, 1000), 64, 10, 60000 * scale, dict(hot=11), dict(hot_mode=1)),
+        ("variable lengths", 3000 * scale, (1, 20), 256, 12, 20000 * scale, dict(var_len=True), dict()),
+        ("long messages", 1500 * scale, (1, 12), 64, 10, 8000 * scale, dict(long_to=4096), dict(max_message=4096)),
+    ]
+    for seed in range(seeds):
+        for name, nb, (lo, hi), stride, rounds, batch, kw, ekw in cases:
+            rng = np.random.default_rng(1000 + seed)
+            ids = [f"s{seed}b{b:x}~t{b:x}" for b in range(nb)] + [f"ghost{k}~x" for k in range(kw.get("unknown", 0))]
+            counts = rng.integers(lo, hi, nb)
+            t0 = time.time()
+            e, o, d = make_pair(oracle_py, ids, stride, capacity=nb + 64, arena=2 << 30, max_batch=1 << 18, **ekw)
+            try:
+                run_oplog(d, rng, nb, counts, stride, rounds=rounds, batch=batch, **kw)
+            finally:
+                e.close()
+            print(f"seed {seed} {name:32s} ok  {time.time() - t0:6.1f} s", flush=True)
+    print("soak ok")
+
+
+if __name__ == "__main__":
+    main()
