@@ -109,6 +109,19 @@ __global__ void rand_rdk_kernel(const uint64_t* __restrict__ tab, uint64_t line_
     if (acc == 0x1234567) out[0] = acc;
 }
 
+// exchange with workgroup scope: the hardware may serve it in the XCD's own L2 (NOT coherent across XCDs;
+// only a yardstick for what a device-wide exchange costs beyond that)
+__global__ void rand_xchg_wg_kernel(uint64_t* __restrict__ tab, uint64_t line_mask, uint32_t n, uint64_t seed,
+                                    uint64_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t line = mix(seed + i) & line_mask;
+    uint64_t v = tab[line * 8];
+    uint32_t old = __hip_atomic_exchange(reinterpret_cast<uint32_t*>(&tab[line * 8 + 3]), i + (uint32_t)v, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (old == 0xfffffff3u) out[0] = old;
+}
+
 __global__ void rand_wr64_kernel(uint4* __restrict__ tab, uint64_t line_mask, uint32_t n, uint64_t seed) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t i = t >> 2, c = t & 3;
@@ -175,6 +188,8 @@ int main() {
         printf("  rand_rmw  : %7.1f us  %.1f G lines/s\n", ms * 1e3, n / ms / 1e6);
         ms = time_ms([&](int r) { rand_xchg_kernel<<<n / 256, 256>>>(tab, line_mask, n, 7777ull * r, out); }, 20);
         printf("  rand_xchg : %7.1f us  %.1f G lines/s\n", ms * 1e3, n / ms / 1e6);
+        ms = time_ms([&](int r) { rand_xchg_wg_kernel<<<n / 256, 256>>>(tab, line_mask, n, 7777ull * r, out); }, 20);
+        printf("  rand_xchg, workgroup scope : %7.1f us\n", ms * 1e3);
         ms = time_ms([&](int r) { rand_amax_kernel<<<n / 256, 256>>>(tab, line_mask, n, 7777ull * r, out, 1); }, 20);
         printf("  rand_rd + max (no return) : %7.1f us\n", ms * 1e3);
         ms = time_ms([&](int r) { rand_amax_kernel<<<n / 256, 256>>>(tab, line_mask, n, 7777ull * r, out, 0); }, 20);
