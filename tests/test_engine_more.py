@@ -609,3 +609,156 @@ def test_config3_full_size_properties():
         assert e.stats()["live"] == 0
     finally:
         e.close()
+
+
+def test_config5_large_properties():
+    """BASELINE config #5's event mix at one GPU's scale, checked from the generator's own arithmetic (no
+    oracle at this size): 1 M barriers of count 16 with 1 KB messages whose join-ids are drawn Zipf(1.2) over
+    1 K ids, 10 % of the joins replayed byte-identically, 1 % re-sent with different bytes, and 1 % of all
+    events aimed at four hot barriers of count 64 that can only complete in the last batch (tens of thousands
+    of overwrites each, the long-chain kernels at full batch size).  Expected: every barrier fires once, in the
+    batch in which its last missing position arrives; each position carries the bytes of the LAST event that
+    reached it up to that batch (HSET semantics, redis.clj:135); later events are answered NOT_FOUND."""
+    import time
+    import torch
+    t_start = time.time()
+    nb, c, P, batch = 1 << 20, 16, 1024, 1 << 20
+    n_hot, c_hot = 4, 64
+    rng = np.random.default_rng(55)
+    w = 1.0 / np.arange(1, 1001) ** 1.2
+    jid = rng.choice(1000, size=nb + n_hot, p=w / w.sum())
+    ids = [f"j{int(j):x}~t{b:x}" for b, j in enumerate(jid)]
+    fps_np = capi.fingerprint_many(ids).view(np.int64)
+    assert len({(int(a), int(b)) for a, b in fps_np[:1000]}) == 1000
+    del ids
+    e = _engine(capacity_barriers=nb + n_hot, arena_bytes=(nb * (c * P + 256)) + (256 << 20), max_count=c_hot,
+                payload_stride=P, max_batch=batch)
+    dev = e.device
+    try:
+        g = torch.Generator(device=dev)
+        g.manual_seed(55)
+        fps = torch.from_numpy(fps_np).to(dev)
+        counts = torch.full((nb + n_hot,), c, dtype=torch.int64, device=dev)
+        counts[nb:] = c_hot
+        offsets = torch.cumsum(counts, 0) - counts
+        cells = int(counts.sum())
+        cell_b = torch.repeat_interleave(torch.arange(nb + n_hot, device=dev), counts)
+        cell_p = torch.arange(cells, device=dev) - offsets[cell_b]
+        # base events: every cell once, except the last position of the hot barriers (appended at the very end)
+        is_hot_last = (cell_b >= nb) & (cell_p == c_hot - 1)
+        base = torch.nonzero(~is_hot_last).reshape(-1)
+        n_base = len(base)
+        n_rep, n_chg, n_hotev = n_base // 10, n_base // 100, n_base // 100
+        rep = base[torch.randint(0, n_base, (n_rep,), device=dev, generator=g)]           # byte-identical replays
+        chg = base[torch.randint(0, n_base, (n_chg,), device=dev, generator=g)]           # same cell, other bytes
+        hot_cell = offsets[nb + torch.randint(0, n_hot, (n_hotev,), device=dev, generator=g)] + \
+            torch.randint(0, c_hot - 1, (n_hotev,), device=dev, generator=g)             # overwrites on the hot barriers
+        ev_cell = torch.cat([base, rep, chg, hot_cell])
+        fresh = torch.cat([torch.zeros(n_base + n_rep, dtype=torch.bool, device=dev),
+                           torch.ones(n_chg + n_hotev, dtype=torch.bool, device=dev)])   # carries bytes of its own
+        perm = torch.randperm(len(ev_cell), device=dev, generator=g)
+        ev_cell, fresh = ev_cell[perm], fresh[perm]
+        ev_cell = torch.cat([ev_cell, torch.nonzero(is_hot_last).reshape(-1)])            # the hot barriers complete last
+        fresh = torch.cat([fresh, torch.zeros(n_hot, dtype=torch.bool, device=dev)])
+        n_events = len(ev_cell)
+        idx = torch.arange(n_events, device=dev)
+        ev_ver = torch.where(fresh, idx + 1, torch.zeros_like(idx))                       # version 0 = the base bytes
+        ev_batch = idx // batch
+        n_batches = int(ev_batch[-1]) + 1
+        # expectations
+        first_batch = torch.full((cells,), 1 << 30, dtype=torch.int64, device=dev).scatter_reduce(0, ev_cell, ev_batch, "amin")
+        fire_batch = torch.zeros(nb + n_hot, dtype=torch.int64, device=dev).scatter_reduce(0, cell_b, first_batch, "amax")
+        assert int(fire_batch.max()) == n_batches - 1
+        applied = ev_batch <= fire_batch[cell_b[ev_cell]]
+        last_idx = torch.full((cells,), -1, dtype=torch.int64, device=dev).scatter_reduce(
+            0, ev_cell[applied], idx[applied], "amax")
+        want_ver = ev_ver[last_idx]
+        del first_batch, last_idx, perm, base, rep, chg, hot_cell
+
+        frecs = torch.empty((nb + n_hot, 4), dtype=torch.int64, device=dev)
+        frecs[:, 0], frecs[:, 1], frecs[:, 2], frecs[:, 3] = fps[:, 0], fps[:, 1], counts, T0 + 3_600_000
+        d_status = torch.empty(batch + n_hot, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        e.fork_batch_dev(batch, frecs[:batch], d_status)
+        e.fork_batch_dev(n_hot, frecs[batch:], d_status[batch:])
+        e.sync()
+        assert bool((d_status == capi.DJ_FORK_CREATED).all())
+        order = torch.argsort(fps[:, 0])
+        sorted_lo = fps[order, 0].contiguous()
+        cap_c, cap_p = 1 << 20, 6_000_000
+        d_conts = torch.empty((cap_c, 8), dtype=torch.int64, device=dev)
+        d_lens = torch.empty(cap_p, dtype=torch.int32, device=dev)
+        d_pay = torch.empty((cap_p, P), dtype=torch.uint8, device=dev)
+        d_res = torch.empty(16, dtype=torch.uint8, device=dev)
+        d_ack = torch.empty(cap_c, dtype=torch.int32, device=dev)
+        d_jst = torch.empty(batch, dtype=torch.int32, device=dev)
+        fired = torch.zeros(nb + n_hot, dtype=torch.int32, device=dev)
+        n_not_found = n_complete_status = 0
+        print(f"\n  generated {n_events} events in {n_batches} batches, {time.time() - t_start:.1f} s", flush=True)
+
+        def payload(b, p, ver):
+            base_ = _splitmix64_t(torch, b * 1024 + p + (ver << 40))
+            k = torch.arange(P // 8, dtype=torch.int64, device=dev) * 0x100000001B3
+            return _splitmix64_t(torch, base_[:, None] + k[None, :]).view(torch.uint8).reshape(len(b), P)
+
+        assert np.array_equal(payload(torch.arange(4, device=dev), torch.arange(4, device=dev), torch.arange(4, device=dev) * 99999).cpu().numpy(),
+                              payload_bytes(np.arange(4), np.arange(4), np.arange(4) * 99999, P))
+
+        for k in range(n_batches):
+            now = T0 + 2 * (k + 1)
+            sl = slice(k * batch, min((k + 1) * batch, n_events))
+            cell = ev_cell[sl]
+            n = len(cell)
+            jb, jp = cell_b[cell], cell_p[cell]
+            recs = torch.empty((n, 4), dtype=torch.int64, device=dev)
+            recs[:, 0], recs[:, 1], recs[:, 2], recs[:, 3] = fps[jb, 0], fps[jb, 1], jp | (P << 32), 0
+            pay = payload(jb, jp, ev_ver[sl])
+            torch.cuda.synchronize()
+            e.join_batch_dev(n, recs, pay, P, now, d_jst)
+            e.sync()
+            st = d_jst[:n]
+            want_nf = ~applied[sl]
+            assert bool(((st == capi.DJ_JOIN_NOT_FOUND) == want_nf).all()), "NOT_FOUND answers differ from the expected late events"
+            assert bool(((st == capi.DJ_JOIN_WAITING) | (st == capi.DJ_JOIN_COMPLETE) | want_nf).all())
+            n_not_found += int(want_nf.sum())
+            n_complete_status += int((st == capi.DJ_JOIN_COMPLETE).sum())
+            del recs, pay
+            while True:
+                res = np.zeros(1, dtype=capi.SWEEP_RESULT)
+                e.sweep_dev(now, cap_c, cap_p, d_conts, d_lens, None, d_pay, d_res, res)
+                rows = int(res[0]["n_conts"])
+                if rows:
+                    cc = d_conts[:rows]
+                    void = ((cc[:, 4] >> 32) & capi.DJ_CONT_VOID) != 0
+                    cc = cc[~void].contiguous()
+                    m = len(cc)
+                    at = torch.searchsorted(sorted_lo, cc[:, 0].contiguous()).clamp_(max=nb + n_hot - 1)
+                    b = order[at]
+                    assert bool((fps[b, 0] == cc[:, 0]).all()) and bool((fps[b, 1] == cc[:, 1]).all())
+                    fired.index_add_(0, b, torch.ones(m, dtype=torch.int32, device=dev))
+                    assert bool((fire_batch[b] == k).all()), "a barrier fired in another batch than the one that completed it"
+                    cnt = cc[:, 4] & 0xFFFFFFFF
+                    assert bool((cnt == counts[b]).all()) and bool(((cc[:, 4] >> 32) == 0).all())
+                    tot = int(cnt.sum())
+                    k_of = torch.repeat_interleave(torch.arange(m, device=dev), cnt)
+                    p_of = torch.arange(tot, device=dev) - (torch.cumsum(cnt, 0) - cnt)[k_of]
+                    row = cc[k_of, 6] + p_of
+                    cellx = offsets[b][k_of] + p_of
+                    assert bool((d_lens[row] == P).all()), "a fired barrier misses a position"
+                    for lo in range(0, tot, 1 << 20):      # in pieces: 1 KB rows
+                        s2 = slice(lo, lo + (1 << 20))
+                        want = payload(b[k_of[s2]], p_of[s2], want_ver[cellx[s2]])
+                        assert bool((d_pay[row[s2]] == want).all()), "a position does not hold its last writer's bytes"
+                    torch.cuda.synchronize()
+                    e.ack_batch_dev(rows, None, d_conts, None, now, d_ack)
+                    e.sync()
+                    assert bool((d_ack[:rows][~void] == capi.DJ_ACK_DONE).all())
+                if not res[0]["more"]:
+                    break
+        print(f"  all batches checked, {time.time() - t_start:.1f} s", flush=True)
+        assert bool((fired == 1).all())
+        assert n_complete_status >= nb + n_hot      # the completing join and every applied replay after it in its batch
+        assert n_not_found > 0
+        assert e.stats()["live"] == 0
+    finally:
+        e.close()
