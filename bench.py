@@ -64,7 +64,7 @@ def cpu_baseline(count, payload):
     """The CPU oracle (a sequential restatement of the reference's core.clj + redis.clj, in-process:
     no Redis round trips, so an upper bound on the reference) on a bounded sample of the workload."""
     from oracle import oracle_py
-    nb = 1 << 18
+    nb = 1 << 19          # half of the GPU job: about 10 s of single-thread work
     ids = make_ids(0, nb)
     o = oracle_py.Oracle(ids, max_count=count, payload_stride=payload)
     rng = np.random.default_rng(2)
@@ -99,7 +99,7 @@ def cpu_baseline_sharded(count, payload):
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle_py
     T = max(1, min(16, len(os.sched_getaffinity(0))))
-    nb = (1 << 18) // T * T
+    nb = (1 << 20) // T * T       # the GPU job's size
     per = nb // T
     ids = make_ids(0, nb)
     shards = [oracle_py.Oracle(ids[t::T], max_count=count, payload_stride=payload) for t in range(T)]
