@@ -85,9 +85,9 @@ void wait_cb(void* user, int32_t status) {
 bool hip_ok(hipError_t r) { return r == hipSuccess; }
 
 // one drain cycle on a closed side
-void apply(dj_batcher* b, Side& s) {
+void apply(dj_batcher* b, Side& s, uint64_t (*clock_fn)(void*), void* clock_user) {
     hipStream_t st = static_cast<hipStream_t>(dj_stream(b->e));
-    const uint64_t now = b->clock_fn(b->clock_user);
+    const uint64_t now = clock_fn(clock_user);
     const uint32_t mb = b->cfg.max_batch;
     int rc = DJ_OK;
     if (s.nf && rc == DJ_OK) {
@@ -150,9 +150,11 @@ void drain_loop(dj_batcher* b) {
         const int cur = b->fill;
         b->fill ^= 1;
         b->first_set = false;
+        uint64_t (*const clock_fn)(void*) = b->clock_fn;     // as set under the mutex; called without it
+        void* const clock_user = b->clock_user;
         lk.unlock();
         b->cv_space.notify_all();
-        apply(b, b->side[cur]);
+        apply(b, b->side[cur], clock_fn, clock_user);
         lk.lock();
     }
 }
