@@ -54,11 +54,17 @@ struct __attribute__((aligned(64))) Slot {
     uint32_t slab;          // arena offset in 64-byte units, 0 = none
     uint32_t chain;         // transient per-batch link head (event index + 1); 0 between batches
     uint64_t deadline;      // :timeout-secs
-    uint64_t join_ts;       // "<id>:join-ts", 0 = nil
     uint64_t join_ts_read;  // "<id>:join-ts-read", 0 = nil
-    uint64_t bits;          // count <= 64: presence bitmap; count > 64: number of present positions
+    uint64_t join_ts;       // "<id>:join-ts", 0 = nil            } the last 16 bytes: what a join batch
+    uint64_t bits;          // count <= 64: presence bitmap;       } rewrites, stored together
+                            // count > 64: number of present positions
 };
 static_assert(sizeof(Slot) == 64, "slot must be one 64-byte line");
+
+// join_ts and bits with one 16-byte store
+__device__ inline void store_ts_bits(Slot* sl, uint64_t join_ts, uint64_t bits) {
+    reinterpret_cast<ulonglong2*>(sl)[3] = make_ulonglong2(join_ts, bits);
+}
 
 __host__ __device__ inline uint64_t q_primary_at(uint64_t v) { return (v >> 63) ? NQ : v; }
 __host__ __device__ inline uint64_t q_backup_at(uint64_t v) { return v == Q_NONE ? NQ : (v & ~Q_POPPED); }

@@ -713,7 +713,7 @@ extern "C" int dj_get_stats(dj_engine* e, dj_stats* h_stats) {
 // ---- durability -----------------------------------------------------------------------------
 namespace {
 struct CkptHeader {
-    char magic[8];               // "DJCKPT3\0"
+    char magic[8];               // "DJCKPT4\0"
     uint64_t slots, arena_units_used, arena_units_total;
     uint32_t stride, max_count;
     uint32_t ring_n[NUM_CLASSES];    // free slabs per class, stored head-first after the arena
@@ -753,7 +753,7 @@ extern "C" int dj_checkpoint_save(dj_engine* e, const char* path) {
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     CkptHeader h;
     memset(&h, 0, sizeof h);
-    memcpy(h.magic, "DJCKPT3", 8);
+    memcpy(h.magic, "DJCKPT4", 8);
     h.slots = e->t.mask + 1;
     h.arena_units_total = e->t.arena_units;
     h.stride = e->t.stride;
@@ -807,7 +807,7 @@ extern "C" int dj_checkpoint_load(dj_engine* e, const char* path) {
     FILE* f = fopen(path, "rb");
     if (!f) return fail(e, DJ_E_INVALID, "checkpoint: cannot open %s", path);
     CkptHeader h;
-    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "DJCKPT3", 8) != 0) {
+    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "DJCKPT4", 8) != 0) {
         fclose(f);
         return fail(e, DJ_E_INVALID, "checkpoint: %s is not a checkpoint file", path);
     }

@@ -295,8 +295,7 @@ __global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint
                     if (!(done & (1u << k)) && idx[k] != 0xFFFFFFFFu && node_pos(nd[k]) == pos) last = false;
                 if (!last) w.dst[best] = NODST;
             }
-            sl->bits = count > 64 ? (uint64_t)r.arrived : r.bits;
-            sl->join_ts = now;                              // SET <id>:join-ts, redis.clj:136
+            store_ts_bits(sl, now, count > 64 ? (uint64_t)r.arrived : r.bits);   // SET <id>:join-ts, redis.clj:136
             sl->chain = 0;
             if (info.y & META_HOT) sl->meta = info.y & ~META_HOT; // a short chain: not hot any more
             if (r.enq) t.q[s] = now;                    // ZADD both at now, redis.clj:257-258
