@@ -88,7 +88,9 @@ class Engine:
         self._check(self.L.dj_sync(self.h))
 
     def torch_stream(self):
-        """The engine's HIP stream as a torch stream (for events / ordering with torch ops)."""
+        """The engine's HIP stream as a torch stream (for events / ordering with torch ops).
+        close() destroys the stream: tensors in pinned memory that were copied on it must be freed before
+        (torch's pinned allocator touches the streams a block was used on when the block is freed)."""
         torch = _torch()
         return torch.cuda.ExternalStream(self.stream_ptr, device=self.device)
 
