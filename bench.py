@@ -345,7 +345,8 @@ def main():
         dom = max((k for k in kernels if kernels[k]["alg_bytes_per_launch"] > 0), key=lambda k: kernels[k]["total_ms"])
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf) and (nb, c, P, world) == (1 << 20, 8, 64, 1):   # the counters were collected on this workload
+        if os.path.exists(tf) and (nb, c, P, world) == (1 << 20, 8, 64, 1) and not routed and a.hot_frac == 0:
+            # the counters were collected on this workload
             with open(tf) as f:
                 traffic = json.load(f).get(dom)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": HBM_PEAK_GBPS,

@@ -149,7 +149,10 @@ struct Work {
 enum { C_COMPLEX = 1, C_MAXCHAIN = 2, C_CXPOOL = 3, C_COUNT = 8 };
 constexpr uint32_t CX_CAP = 65536;     // barriers with long chains per batch handled by the parallel path
 constexpr uint32_t CX_HASH = 262144;   // power of two, >= 2 * CX_CAP
-constexpr uint32_t CX_HOT_STRIDE = 8;  // pool entries per position of a barrier flagged hot (one 64-byte line)
+constexpr uint32_t CX_HOT_STRIDE = 8;  // pool entries per table line (64 bytes)
+constexpr uint32_t CX_HOT_REPL = 16;   // a barrier flagged hot gets this many lines per position: its events spread their
+                                       // atomics over them by wave, the finalize pass folds them into the first
+constexpr uint32_t CX_HOT_SPAN = CX_HOT_STRIDE * CX_HOT_REPL;   // pool entries per position of a hot barrier
 constexpr uint32_t CX_POOL = 1u << 24; // positions of all of them together (the rest takes the serial kernel)
 constexpr uint32_t IDX_NONE = 0xFFFFFFFFu;
 // sweep scratch: S_CURSOR packs both output cursors so a block takes its output range with one

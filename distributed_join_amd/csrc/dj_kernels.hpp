@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(256) cx_init_kernel(Table t, Work w) {
         }
         // a barrier already known to be hot spreads its positions over one 64-byte line each: thousands
         // of atomics on ONE line would queue up
-        const uint32_t share = hot ? count * CX_HOT_STRIDE : count;
+        const uint32_t share = hot ? count * CX_HOT_SPAN : count;
         const uint32_t incl = wave_incl_scan(share);
         const uint32_t total = __shfl(incl, 63);
         uint32_t base = 0;
@@ -484,7 +484,9 @@ __global__ void __launch_bounds__(256) cx_scan_kernel(Work w, uint32_t n, uint64
             if (d != NODST) c = cx_lookup(w, (uint32_t)d);
             if (c != IDX_NONE) {
                 const uint64_t x = w.node[i];
-                key = w.cx_off[c] + node_pos(x) * (w.cx_hot[c] ? CX_HOT_STRIDE : 1u);   // first and last index share 8 bytes
+                // first and last index share 8 bytes; a hot barrier's position has CX_HOT_REPL lines, picked by wave
+                key = w.cx_hot[c] ? w.cx_off[c] + node_pos(x) * CX_HOT_SPAN + (uint32_t)((base >> 6) & (CX_HOT_REPL - 1)) * CX_HOT_STRIDE
+                                  : w.cx_off[c] + node_pos(x);
                 mw = node_mw(x);
             }
         }
@@ -528,14 +530,27 @@ __global__ void __launch_bounds__(64) cx_finalize_kernel(Table t, Work w, uint64
         Slot* sl = &t.slots[s];
         const uint32_t count = sl->count, slab = sl->slab;
         const uint64_t bits_pre = sl->bits;
-        const uint32_t pstride = w.cx_hot[c] ? CX_HOT_STRIDE : 1u;
+        const bool hot = w.cx_hot[c] != 0;
+        const uint32_t pstride = hot ? CX_HOT_SPAN : 1u;
         uint32_t t_complete = 0, n_new = 0;
         uint64_t bits0 = bits_pre;
         const uint32_t words = (count + 63) >> 6;
         for (uint32_t wd = 0; wd < words; ++wd) {
             const uint32_t p = wd * 64 + lane;
             const uint64_t word = count > 64 ? slab_bitmap(t, slab)[wd] : bits_pre;
-            const uint32_t f = p < count ? w.cx_mm[off + p * pstride].x : IDX_NONE;
+            uint32_t f = IDX_NONE;
+            if (p < count) {
+                uint2 mm = w.cx_mm[off + p * pstride];
+                if (hot) {      // fold the position's lines into the first: the copy pass reads the last index there
+                    for (uint32_t r = 1; r < CX_HOT_REPL; ++r) {
+                        const uint2 o = w.cx_mm[off + p * pstride + r * CX_HOT_STRIDE];
+                        if (o.x < mm.x) mm.x = o.x;
+                        if (o.y > mm.y) mm.y = o.y;
+                    }
+                    w.cx_mm[off + p * pstride] = mm;
+                }
+                f = mm.x;
+            }
             const bool fresh = f != IDX_NONE && !((word >> lane) & 1);
             if (fresh && f > t_complete) t_complete = f;
             const uint64_t add = __ballot(fresh);
@@ -605,7 +620,7 @@ __global__ void __launch_bounds__(256) join_copy_kernel(Table t, Work w, const d
                     if (T != IDX_NONE && i >= T) status[i] = DJ_JOIN_COMPLETE;
                     else if (b.z && w.cx_nq[c]) status[i] = DJ_JOIN_NEAREST_NOT_QUEUED;
                 }
-                if (w.cx_mm[w.cx_off[c] + b.x * (w.cx_hot[c] ? CX_HOT_STRIDE : 1u)].y != (uint32_t)i + 1) continue;   // a later event of the batch wrote this position
+                if (w.cx_mm[w.cx_off[c] + b.x * (w.cx_hot[c] ? CX_HOT_SPAN : 1u)].y != (uint32_t)i + 1) continue;   // a later event of the batch wrote this position
             }
         }
         if (j0 == 0 && (d & DST_PM)) slab_posmeta(t, slab, k)[b.x] = make_uint2(b.y, b.z);
@@ -651,7 +666,7 @@ __global__ void __launch_bounds__(256) join_copy_long_kernel(Table t, Work w, co
                         if (T != IDX_NONE && i >= T) status[i] = DJ_JOIN_COMPLETE;
                         else if (b.z && w.cx_nq[c]) status[i] = DJ_JOIN_NEAREST_NOT_QUEUED;
                     }
-                    if (w.cx_mm[w.cx_off[c] + b.x * (w.cx_hot[c] ? CX_HOT_STRIDE : 1u)].y != (uint32_t)i + 1) live = false;
+                    if (w.cx_mm[w.cx_off[c] + b.x * (w.cx_hot[c] ? CX_HOT_SPAN : 1u)].y != (uint32_t)i + 1) live = false;
                 }
             }
         }
