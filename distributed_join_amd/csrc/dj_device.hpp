@@ -132,6 +132,8 @@ struct Work {
     uint32_t* cont_slot; // sweep: slot of continuation k
     unsigned int* counters;       // C_* below, bank of the current join batch
     unsigned int* counters_next;  // the other bank: zeroed by the current batch for the next one
+    unsigned int* hint;           // pinned HOST memory: [0] barriers with long chains, [1] longest chain of the latest
+                                  // join batch, written by its last kernel (the host reads them without waiting)
     unsigned long long* sweep;    // S_* below, bank of the current sweep
     unsigned long long* sweep_next;
     // hot-barrier path (barriers with long chains), see the cx_* kernels

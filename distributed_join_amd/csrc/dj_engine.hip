@@ -250,6 +250,7 @@ static int create_impl(dj_engine* e) {
     w.cx_on = 0;
     HIP_TRY(e, hipHostMalloc((void**)&e->h_maxchain, 64, hipHostMallocDefault));
     e->h_maxchain[0] = e->h_maxchain[1] = 0;
+    w.hint = e->h_maxchain;       // hipHostMalloc memory is addressable from the device
     ALLOC(e, e->d_sweep, 2 * S_COUNT * 8);
     HIP_TRY(e, hipMemsetAsync(e->d_sweep, 0, 2 * S_COUNT * 8, e->stream));
     e->ctr_bank = e->sweep_bank = 0;
@@ -501,7 +502,6 @@ extern "C" int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs
     else if (lanes <= 16) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<16>(e, n, d_recs, d_payloads, pitch, d_status));
     else if (lanes <= 32) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<32>(e, n, d_recs, d_payloads, pitch, d_status));
     else LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<64>(e, n, d_recs, d_payloads, pitch, d_status));
-    HIP_TRY(e, hipMemcpyAsync(e->h_maxchain, &e->w.counters[C_COMPLEX], 8, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipGetLastError());
     return DJ_OK;
 }

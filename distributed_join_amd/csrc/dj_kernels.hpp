@@ -601,6 +601,10 @@ __global__ void __launch_bounds__(256) join_copy_kernel(Table t, Work w, const d
     const uint64_t waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     // the next batch's counters (the bank this batch does not use) start at zero
     if (blockIdx.x == 0 && threadIdx.x < C_COUNT) w.counters_next[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {      // final since the resolve passes; straight into the host's memory
+        w.hint[0] = w.counters[C_COMPLEX];
+        w.hint[1] = w.counters[C_MAXCHAIN];
+    }
     const bool hot = w.cx_on && w.counters[C_COMPLEX] != 0;
     for (uint64_t base = wave * EPW; base < n; base += waves * EPW) {
         const uint64_t i = base + sub;
@@ -645,6 +649,10 @@ __global__ void __launch_bounds__(256) join_copy_long_kernel(Table t, Work w, co
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     if (blockIdx.x == 0 && threadIdx.x < C_COUNT) w.counters_next[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {      // final since the resolve passes; straight into the host's memory
+        w.hint[0] = w.counters[C_COMPLEX];
+        w.hint[1] = w.counters[C_MAXCHAIN];
+    }
     const bool hot = w.cx_on && w.counters[C_COMPLEX] != 0;
     for (uint64_t base = wave * EPW; base < n; base += waves * EPW) {      // uniform across the wave
         const uint64_t i = base + sub;
