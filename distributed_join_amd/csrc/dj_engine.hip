@@ -527,10 +527,13 @@ static void launch_gather(dj_engine* e, const dj_cont* conts, int from_sweep, ui
 static void dispatch_gather(dj_engine* e, const dj_cont* conts, int from_sweep, uint32_t n_fixed, uint32_t cap_conts,
                             uint64_t cap_pos, int update_ts, uint32_t* lens, uint32_t* mws, uint8_t* payloads,
                             dj_sweep_result* res) {
-    // lanes per continuation from the largest continuation the engine can hold (16-byte chunks)
+    // lanes per continuation from the largest continuation the engine can hold (16-byte chunks).  Rows of
+    // 256 bytes and more go to whole waves earlier: measured at count 16 x 256 B, 82 -> 59 us per 32 K
+    // continuations; with 64-byte rows and many small barriers 16 lanes stay better up to 512 chunks
     const uint64_t items = (uint64_t)e->cfg.max_count * (e->cfg.payload_stride / 16);
+    const uint64_t wave_from = e->cfg.payload_stride >= 256 ? 128 : 512;
     if (items <= 16) launch_gather<8>(e, conts, from_sweep, n_fixed, cap_conts, cap_pos, update_ts, lens, mws, payloads, res);
-    else if (items <= 512) launch_gather<16>(e, conts, from_sweep, n_fixed, cap_conts, cap_pos, update_ts, lens, mws, payloads, res);
+    else if (items <= wave_from) launch_gather<16>(e, conts, from_sweep, n_fixed, cap_conts, cap_pos, update_ts, lens, mws, payloads, res);
     else launch_gather<64>(e, conts, from_sweep, n_fixed, cap_conts, cap_pos, update_ts, lens, mws, payloads, res);
 }
 
