@@ -512,29 +512,19 @@ static uint32_t pop_blocks(const dj_engine* e) {
     return (uint32_t)b;
 }
 
-template <int GS>
-static void launch_gather(dj_engine* e, const dj_cont* conts, int from_sweep, uint32_t n_fixed, uint32_t cap_conts,
-                          uint64_t cap_pos, int update_ts, uint32_t* lens, uint32_t* mws, uint8_t* payloads,
-                          dj_sweep_result* res) {
-    const uint64_t n = from_sweep ? cap_conts : n_fixed;
-    uint64_t blocks = (n * GS + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    if (blocks < 1) blocks = 1;
-    gather_kernel<GS><<<(uint32_t)blocks, 256, 0, e->stream>>>(e->t, e->w, conts, from_sweep, n_fixed, cap_conts, cap_pos,
-                                                                update_ts, lens, mws, payloads, res);
-}
-
 static void dispatch_gather(dj_engine* e, const dj_cont* conts, int from_sweep, uint32_t n_fixed, uint32_t cap_conts,
                             uint64_t cap_pos, int update_ts, uint32_t* lens, uint32_t* mws, uint8_t* payloads,
                             dj_sweep_result* res) {
-    // lanes per continuation from the largest continuation the engine can hold (16-byte chunks).  Rows of
-    // 256 bytes and more go to whole waves earlier: measured at count 16 x 256 B, 82 -> 59 us per 32 K
-    // continuations; with 64-byte rows and many small barriers 16 lanes stay better up to 512 chunks
+    // a listed continuation (snapshot) gets lanes by the largest continuation the engine can hold; after a
+    // sweep the kernel decides from what was popped
     const uint64_t items = (uint64_t)e->cfg.max_count * (e->cfg.payload_stride / 16);
-    const uint64_t wave_from = e->cfg.payload_stride >= 256 ? 128 : 512;
-    if (items <= 16) launch_gather<8>(e, conts, from_sweep, n_fixed, cap_conts, cap_pos, update_ts, lens, mws, payloads, res);
-    else if (items <= wave_from) launch_gather<16>(e, conts, from_sweep, n_fixed, cap_conts, cap_pos, update_ts, lens, mws, payloads, res);
-    else launch_gather<64>(e, conts, from_sweep, n_fixed, cap_conts, cap_pos, update_ts, lens, mws, payloads, res);
+    const int gs_fixed = items <= 16 ? 8 : items < 96 ? 16 : 64;
+    const uint64_t n = from_sweep ? cap_conts : n_fixed;
+    uint64_t blocks = (n * 64 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    gather_kernel<<<(uint32_t)blocks, 256, 0, e->stream>>>(e->t, e->w, conts, from_sweep, n_fixed, cap_conts, cap_pos,
+                                                            update_ts, lens, mws, payloads, res, gs_fixed);
 }
 
 static int sweep_impl(dj_engine* e, const char* what, uint64_t now_ms, uint32_t cap_conts, uint64_t cap_positions,
@@ -641,8 +631,8 @@ extern "C" int dj_snapshot_one(dj_engine* e, uint64_t fp_lo, uint64_t fp_hi, int
     std::lock_guard<std::recursive_mutex> guard(e->mu);
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     lookup_one_kernel<<<1, 64, 0, e->stream>>>(e->t, e->w, fp_lo, fp_hi, e->d_one_cont, e->d_one_scores);
-    gather_kernel<64><<<1, 64, 0, e->stream>>>(e->t, e->w, e->d_one_cont, 0, 1, 1, e->cfg.max_count, update_ts ? 1 : 0,
-                                               e->d_one_lens, e->d_one_mws, h_payloads ? e->d_one_payload : nullptr, nullptr);
+    gather_kernel<<<1, 64, 0, e->stream>>>(e->t, e->w, e->d_one_cont, 0, 1, 1, e->cfg.max_count, update_ts ? 1 : 0,
+                                           e->d_one_lens, e->d_one_mws, h_payloads ? e->d_one_payload : nullptr, nullptr, 64);
     HIP_TRY(e, hipGetLastError());
     HIP_TRY(e, hipMemcpyAsync(h_meta, e->d_one_cont, sizeof(dj_cont), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));

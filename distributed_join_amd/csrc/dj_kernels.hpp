@@ -885,21 +885,11 @@ __global__ void finish_result_kernel(Work w, dj_sweep_result* res, uint32_t cap_
     if (threadIdx.x == 0 && blockIdx.x == 0) publish_result(w, res, cap_conts, cap_pos);
 }
 
-// redis/all-joins for popped barriers (from_sweep: the raw cursor says how many; it also
-// publishes the sweep's result block) or for n_fixed listed continuations.  GS lanes work on
-// one continuation, 64 / GS continuations per wave are in flight together: the pass is bound
-// by chains of dependent loads (continuation -> slot -> slab), not by bytes.
-// update_ts: join-ts-read := join-ts (redis.clj:222-229).
+// redis/all-joins for n continuations.  GS lanes work on one continuation, 64 / GS continuations per
+// wave are in flight together.  update_ts: join-ts-read := join-ts (redis.clj:222-229).
 template <int GS>
-__global__ void __launch_bounds__(256) gather_kernel(Table t, Work w, const dj_cont* conts, int from_sweep,
-                                                     uint32_t n_fixed, uint32_t cap_conts, uint64_t cap_pos,
-                                                     int update_ts, uint32_t* lens, uint32_t* max_waits,
-                                                     uint8_t* payloads, dj_sweep_result* res) {
-    uint32_t n = n_fixed;
-    if (from_sweep) {
-        const unsigned long long nc = w.sweep[S_CURSOR] & CURSOR_CONT_MASK;
-        n = nc > cap_conts ? cap_conts : (uint32_t)nc;
-    }
+__device__ inline void gather_body(const Table& t, const Work& w, const dj_cont* conts, uint32_t n, int update_ts,
+                                   uint32_t* lens, uint32_t* max_waits, uint8_t* payloads) {
     const uint64_t gtid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
     const uint64_t group = gtid / GS, groups = ((uint64_t)gridDim.x * blockDim.x) / GS;
     const uint32_t j = (uint32_t)(gtid % GS);
@@ -937,7 +927,29 @@ __global__ void __launch_bounds__(256) gather_kernel(Table t, Work w, const dj_c
                      nt_load(&reinterpret_cast<const uint4*>(pay + (uint64_t)p * t.stride)[ch]));
         }
     }
-    if (from_sweep && res && gtid == 0) publish_result(w, res, cap_conts, cap_pos);
+}
+
+// The gather pass for popped barriers (from_sweep: the raw cursor says how many; the pass also publishes
+// the sweep's result block) or for n_fixed listed continuations.  Lanes per continuation: after a sweep
+// from what was actually popped (16-byte chunks per continuation on average: whole waves from 96 on,
+// measured on counts 4..64 x 64..1024 bytes), else the caller's choice.
+__global__ void __launch_bounds__(256) gather_kernel(Table t, Work w, const dj_cont* conts, int from_sweep,
+                                                     uint32_t n_fixed, uint32_t cap_conts, uint64_t cap_pos,
+                                                     int update_ts, uint32_t* lens, uint32_t* max_waits,
+                                                     uint8_t* payloads, dj_sweep_result* res, int gs_fixed) {
+    uint32_t n = n_fixed;
+    int gs = gs_fixed;
+    if (from_sweep) {
+        const unsigned long long cur = w.sweep[S_CURSOR];
+        const unsigned long long nc = cur & CURSOR_CONT_MASK, np = cur >> CURSOR_SHIFT;
+        n = nc > cap_conts ? cap_conts : (uint32_t)nc;
+        const unsigned long long chunks = nc ? np * (t.stride >> 4) / nc : 0;
+        gs = chunks >= 96 ? 64 : chunks > 16 ? 16 : 8;
+    }
+    if (gs == 64) gather_body<64>(t, w, conts, n, update_ts, lens, max_waits, payloads);
+    else if (gs == 16) gather_body<16>(t, w, conts, n, update_ts, lens, max_waits, payloads);
+    else gather_body<8>(t, w, conts, n, update_ts, lens, max_waits, payloads);
+    if (from_sweep && res && blockIdx.x == 0 && threadIdx.x == 0) publish_result(w, res, cap_conts, cap_pos);
 }
 
 // =====================================================================================
