@@ -630,8 +630,10 @@ __global__ void __launch_bounds__(256) join_copy_kernel(Table t, Work w, const d
         if (j0 == 0 && (d & DST_PM)) slab_posmeta(t, slab, k)[b.x] = make_uint2(b.y, b.z);
         const uint4* src = reinterpret_cast<const uint4*>(payloads + i * pitch);
         uint4* dstp = reinterpret_cast<uint4*>(slab_payload(t, slab, k) + (uint64_t)b.x * t.stride);
-        const uint32_t chunks = (b.y + 15) >> 4;
-        for (uint32_t c = j0; c < chunks; c += G) nt_store(&dstp[c], nt_load(&src[c]));
+        // the row is written in whole 64-byte lines (zeros behind the message): a partly written line costs a
+        // read-modify-write in memory; the row itself is a multiple of 64 bytes
+        const uint32_t chunks = (b.y + 15) >> 4, full = (chunks + 3) & ~3u;
+        for (uint32_t c = j0; c < full; c += G) nt_store(&dstp[c], c < chunks ? nt_load(&src[c]) : make_uint4(0, 0, 0, 0));
     }
 }
 
@@ -721,8 +723,8 @@ __global__ void __launch_bounds__(256) join_copy_long_kernel(Table t, Work w, co
         if (live && !new_long) {
             const uint4* src = reinterpret_cast<const uint4*>(payloads + i * pitch);
             uint4* dstp = reinterpret_cast<uint4*>(slab_payload(t, slab, k) + (uint64_t)b.x * t.stride);
-            const uint32_t chunks = (b.y + 15) >> 4;
-            for (uint32_t c = j0; c < chunks; c += G) nt_store(&dstp[c], nt_load(&src[c]));
+            const uint32_t chunks = (b.y + 15) >> 4, full = (chunks + 3) & ~3u;     // whole lines, as in join_copy
+            for (uint32_t c = j0; c < full; c += G) nt_store(&dstp[c], c < chunks ? nt_load(&src[c]) : make_uint4(0, 0, 0, 0));
         }
         // long messages: the whole wave copies one after the other
         uint64_t todo = __ballot(lead && new_long && unit_new != 0);
@@ -922,9 +924,12 @@ __device__ inline void gather_body(const Table& t, const Work& w, const dj_cont*
             const bool present = count > 64 ? ((bm[p >> 6] >> (p & 63)) & 1) : ((bits0 >> p) & 1);
             if (!present) continue;
             const uint32_t len = stored_meta ? pm[p].x : t.stride;   // a long message leaves its 16-byte reference in the row
-            if (ch >= (len > t.stride ? 1u : ((len + 15) >> 4))) continue;
+            // whole 64-byte lines of the caller's row are written (zeros behind the message), never a part of one
+            const uint32_t chunks = len > t.stride ? 1u : ((len + 15) >> 4);
+            if (ch >= ((chunks + 3) & ~3u)) continue;
             nt_store(&reinterpret_cast<uint4*>(payloads + (pos_base + p) * (uint64_t)t.stride)[ch],
-                     nt_load(&reinterpret_cast<const uint4*>(pay + (uint64_t)p * t.stride)[ch]));
+                     ch < chunks ? nt_load(&reinterpret_cast<const uint4*>(pay + (uint64_t)p * t.stride)[ch])
+                                 : make_uint4(0, 0, 0, 0));
         }
     }
 }

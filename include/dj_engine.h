@@ -198,7 +198,8 @@ int dj_pop_due(dj_engine* e, uint64_t now_ms, uint32_t cap_conts,
  * (redis.clj:210-243): join-ts-read := join-ts, messages gathered in position order.
  * Position p of continuation k: d_lens[pos_base+p] = message length or DJ_NIL when the
  * position is missing; d_max_waits[...] = its :max-wait (0 absent; may be NULL);
- * bytes at d_payloads + (pos_base+p) * payload_stride.  A barrier is popped only if its
+ * bytes at d_payloads + (pos_base+p) * payload_stride (the row may be zero-filled behind the message up
+ * to the next 64-byte boundary).  A barrier is popped only if its
  * count still fits under cap_positions; one that does not may leave a DJ_CONT_VOID row among the
  * n_conts rows written.  h_result (optional) makes the call synchronous. */
 int dj_sweep(dj_engine* e, uint64_t now_ms, uint32_t cap_conts, uint64_t cap_positions,
