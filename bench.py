@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="functional rehearsal of the N>1 path on a box with ONE GPU: all ranks share device 0 and the "
                          "collectives go over gloo (RCCL refuses two ranks on one device); not a measurement")
+    ap.add_argument("--max-message", type=int, default=0,
+                    help="experiment: create the engine with messages up to this many bytes accepted (longer than a row: "
+                         "blocks of their own); the bench's messages stay inline, the long-message kernels run")
     ap.add_argument("--route", action="store_true",
                     help="run the multi-GPU routing path (partition + all-to-all) even with one rank")
     return ap.parse_args()
@@ -203,7 +206,8 @@ def main():
     # capacity nb -> 2 * nb slots at every N (a rank owns nb +- 0.3 % of the global barrier space)
     eng = Engine(capacity_barriers=nb,
                  arena_bytes=int(nb * (1.0 if world == 1 else 1.3) * (slab_bytes + 64)) + (64 << 20), max_count=c,
-                 payload_stride=stride, max_batch=max(recv_cap, nb * 2 if world > 1 else nb), device=local)
+                 payload_stride=stride, max_batch=max(recv_cap, nb * 2 if world > 1 else nb), device=local,
+                 max_message_bytes=a.max_message)
     cap_conts = int(nb * (1.0 if world == 1 else 1.3)) + 1024
     cap_pos = cap_conts * c
     d_conts = eng.empty(cap_conts * capi.CONT.itemsize)
@@ -345,7 +349,7 @@ def main():
         dom = max((k for k in kernels if kernels[k]["alg_bytes_per_launch"] > 0), key=lambda k: kernels[k]["total_ms"])
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf) and (nb, c, P, world) == (1 << 20, 8, 64, 1) and not routed and a.hot_frac == 0:
+        if os.path.exists(tf) and (nb, c, P, world) == (1 << 20, 8, 64, 1) and not routed and a.hot_frac == 0 and not a.max_message:
             # the counters were collected on this workload
             with open(tf) as f:
                 traffic = json.load(f).get(dom)

@@ -160,7 +160,8 @@ join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t 
             // {len, max_wait} of a position is stored only when it differs from a full row without max-wait,
             // or when the barrier has seen such a position before (META_PMD, sticky until the next fork)
             const bool pm = (info.y & META_PMD) || b.y != t.stride || b.z != 0;
-            w.dst[i] = dst_pack(info.z, info.x, b.x) | (pm ? DST_PM : 0ull) | (b.y == t.stride ? DST_FULL : 0ull);
+            w.dst[i] = dst_pack(info.z, info.x, b.x) | (pm ? DST_PM : 0ull) | (b.y == t.stride ? DST_FULL : 0ull) |
+                       ((info.y & META_OVF) ? DST_OVF : 0ull);
             if (pm && !(info.y & META_PMD)) atomicOr(&t.slots[s].meta, META_PMD);
             slot = (uint32_t)s;
             w.ev_slot[i] = slot;
@@ -667,7 +668,8 @@ __global__ void __launch_bounds__(256) join_copy_long_kernel(Table t, Work w, co
         }
         const uint32_t slab = (uint32_t)d, k = live ? dst_class(d) : 0;
         if (live) {
-            b = reinterpret_cast<const uint4*>(recs)[2 * i + 1];   // position, len, max_wait
+            b = make_uint4(dst_pos(d), t.stride, 0, 0);            // position, len, max_wait
+            if (hot || (d & DST_PM) || !(d & DST_FULL)) b = reinterpret_cast<const uint4*>(recs)[2 * i + 1];
             if (hot) {
                 const uint32_t c = cx_lookup(w, slab);
                 if (c != IDX_NONE) {
@@ -688,7 +690,8 @@ __global__ void __launch_bounds__(256) join_copy_long_kernel(Table t, Work w, co
         uint8_t* row = nullptr;
         if (lead) {
             row = slab_payload(t, slab, k) + (uint64_t)b.x * t.stride;
-            const uint32_t old_len = slab_posmeta(t, slab, k)[b.x].x;
+            // only a barrier that held long messages before this batch can have one at this position
+            const uint32_t old_len = (d & DST_OVF) ? slab_posmeta(t, slab, k)[b.x].x : 0u;
             const bool old_long = old_len > t.stride && old_len != DJ_NIL;
             if (old_long) {
                 const dj_long_ref ref = *reinterpret_cast<const dj_long_ref*>(row);
@@ -712,7 +715,7 @@ __global__ void __launch_bounds__(256) join_copy_long_kernel(Table t, Work w, co
                 status[i] = DJ_JOIN_NO_SPACE;
                 len = 0;
             }
-            slab_posmeta(t, slab, k)[b.x] = make_uint2(len, b.z);
+            if (d & DST_PM) slab_posmeta(t, slab, k)[b.x] = make_uint2(len, b.z);    // always set for a long message
             if (new_long && unit_new != 0) {
                 dj_long_ref ref;
                 ref.unit = unit_new; ref.size_class = k_new; ref.len = b.y; ref.zero = 0;
