@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--max-message", type=int, default=0,
                     help="experiment: create the engine with messages up to this many bytes accepted (longer than a row: "
                          "blocks of their own); the bench's messages stay inline, the long-message kernels run")
+    ap.add_argument("--max-count", type=int, default=0,
+                    help="experiment: the engine's :fork-count-max (default: the job's count)")
     ap.add_argument("--route", action="store_true",
                     help="run the multi-GPU routing path (partition + all-to-all) even with one rank")
     return ap.parse_args()
@@ -205,7 +207,8 @@ def main():
     recv_cap = batch if world == 1 else int(batch * 1.25) + 4096       # hash imbalance headroom
     # capacity nb -> 2 * nb slots at every N (a rank owns nb +- 0.3 % of the global barrier space)
     eng = Engine(capacity_barriers=nb,
-                 arena_bytes=int(nb * (1.0 if world == 1 else 1.3) * (slab_bytes + 64)) + (64 << 20), max_count=c,
+                 arena_bytes=int(nb * (1.0 if world == 1 else 1.3) * (slab_bytes + 64)) + (64 << 20),
+                 max_count=max(c, a.max_count),
                  payload_stride=stride, max_batch=max(recv_cap, nb * 2 if world > 1 else nb), device=local,
                  max_message_bytes=a.max_message)
     cap_conts = int(nb * (1.0 if world == 1 else 1.3)) + 1024
@@ -349,7 +352,7 @@ def main():
         dom = max((k for k in kernels if kernels[k]["alg_bytes_per_launch"] > 0), key=lambda k: kernels[k]["total_ms"])
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf) and (nb, c, P, world) == (1 << 20, 8, 64, 1) and not routed and a.hot_frac == 0 and not a.max_message:
+        if os.path.exists(tf) and (nb, c, P, world) == (1 << 20, 8, 64, 1) and not routed and a.hot_frac == 0 and not a.max_message and not a.max_count:
             # the counters were collected on this workload
             with open(tf) as f:
                 traffic = json.load(f).get(dom)
