@@ -48,6 +48,8 @@ def parse():
                          "blocks of their own); the bench's messages stay inline, the long-message kernels run")
     ap.add_argument("--max-count", type=int, default=0,
                     help="experiment: the engine's :fork-count-max (default: the job's count)")
+    ap.add_argument("--join-max-wait", type=int, default=0,
+                    help="experiment: every join carries this max-wait in seconds (store-nearest path)")
     ap.add_argument("--route", action="store_true",
                     help="run the multi-GPU routing path (partition + all-to-all) even with one rank")
     return ap.parse_args()
@@ -193,7 +195,7 @@ def main():
     recs[:, 0] = fps[b_of, 0]
     recs[:, 1] = fps[b_of, 1]
     recs[:, 2] = p_of | (P << 32)          # position | len << 32
-    recs[:, 3] = 0                          # max_wait_s, reserved
+    recs[:, 3] = a.join_max_wait            # max_wait_s, reserved
     payloads = torch.randint(0, 256, (nb * c, pitch), dtype=torch.uint8, device=dev, generator=g)
     fork_recs = torch.empty((nb, 4), dtype=torch.int64, device=dev)                # dj_fork_rec
     fork_recs[:, 0] = fps[:, 0]
@@ -352,7 +354,7 @@ def main():
         dom = max((k for k in kernels if kernels[k]["alg_bytes_per_launch"] > 0), key=lambda k: kernels[k]["total_ms"])
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf) and (nb, c, P, world) == (1 << 20, 8, 64, 1) and not routed and a.hot_frac == 0 and not a.max_message and not a.max_count:
+        if os.path.exists(tf) and (nb, c, P, world) == (1 << 20, 8, 64, 1) and not routed and a.hot_frac == 0 and not a.max_message and not a.max_count and not a.join_max_wait:
             # the counters were collected on this workload
             with open(tf) as f:
                 traffic = json.load(f).get(dom)
