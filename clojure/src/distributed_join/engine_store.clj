@@ -151,7 +151,8 @@
       (check (native-int dj "dj_batcher_fork_wait" @batcher rec status) "dj_batcher_fork_wait")
       (if (= 1 (.getInt status 0))                                     ; DJ_FORK_CREATED
         barrier-id
-        (throw (ex-info "Database failure(s)" {:causes [(str "engine limit reached: " (.getInt status 0))]}))))))
+        (do (.remove forks fp)
+            (throw (ex-info "Database failure(s)" {:causes [(str "engine limit reached: " (.getInt status 0))]})))))))
 
 (defn join
   "record: the Join map (store.clj:19-28).  Deferred of {:complete? bool}; 404 / 400 as error
@@ -189,7 +190,7 @@
             (when-not (= len -1)                                       ; DJ_NIL
               (let [wait (.getInt waits (* 4 i))]
                 (cond-> {:barrier-id barrier-id :position p
-                         :message (String. (.getByteArray payloads (* payload-stride i) len) StandardCharsets/UTF_8)}
+                         :message (String. (.getByteArray payloads (long (* payload-stride i)) (int len)) StandardCharsets/UTF_8)}
                   (pos? wait) (assoc :max-wait wait))))))
         (range cnt)))
 
@@ -215,7 +216,8 @@
 (defn sweep
   "One poll of the publisher (core.clj:180-188 up to the POST).  Deferred of a vector of
   {:barrier-id :metadata :timeout? :messages [...] :index row}; :metadata is nil for an id that was
-  queued without metadata (core.clj:159-161).  Call ack with the same vector before the next sweep."
+  queued without metadata (core.clj:159-161; its :barrier-id is nil too when this JVM never saw the fork: the
+  engine keeps fingerprints, not id strings).  Call ack with the same vector before the next sweep."
   [now-ms]
   (deferred/future
     (locking publisher-lock
