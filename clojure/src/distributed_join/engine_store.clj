@@ -146,12 +146,12 @@
                 (.setLong 0 lo) (.setLong 8 hi)
                 (.setInt 16 (int (:count record))) (.setInt 20 (int 0))
                 (.setLong 24 (long (:timeout-secs record))))
-          status (Memory. 4)]
-      (.put forks fp (assoc record :barrier-id barrier-id))            ; before the engine can pop it
+          status (Memory. 4)
+          previous (.put forks fp (assoc record :barrier-id barrier-id))]   ; before the engine can pop it
       (check (native-int dj "dj_batcher_fork_wait" @batcher rec status) "dj_batcher_fork_wait")
       (if (= 1 (.getInt status 0))                                     ; DJ_FORK_CREATED
         barrier-id
-        (do (.remove forks fp)
+        (do (if previous (.put forks fp previous) (.remove forks fp))    ; a refused fork leaves the barrier as it was
             (throw (ex-info "Database failure(s)" {:causes [(str "engine limit reached: " (.getInt status 0))]})))))))
 
 (defn join
