@@ -248,7 +248,10 @@ def main():
         dbg("step", k)
         if s == 0:
             if router is None:
-                eng.fork_batch_dev(nb, fork_recs, d_status)
+                # the hot key (barrier 0) is forked once and stays: re-forking it would clear what the engine has
+                # learnt about it, which is not what a barrier under a replay storm looks like
+                lo_f = 1 if (a.hot_frac > 0 and k >= steps_per_job) else 0
+                eng.fork_batch_dev(nb - lo_f, fork_recs[lo_f:], d_status)
             else:
                 h = pending_fork.pop(0) if pending_fork else router.start(fork_recs, None, nb)
                 r_recs, _, n_in = router.finish(h)
@@ -330,7 +333,7 @@ def main():
         if rank == 0:
             eng.profile_enable(True)
         for k in range(steps_per_job):
-            step(k, prefetch=0)
+            step(k + steps_per_job, prefetch=0)      # not the first job: a hot key, if any, is not forked again
             if rank == 0:
                 for name, ms in eng.profile_read().items():
                     acc.setdefault(name, []).append(ms)

@@ -121,7 +121,7 @@ join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t 
     // Block-level pre-aggregation for barriers flagged hot: their events are chained inside the block
     // through LDS and the block issues ONE exchange per hot barrier (a contended returning atomic
     // costs ~60 ns, ten thousand of them on one word would serialise the whole pass).
-    constexpr int HOT_KEYS = 8, HOT_LIST = 128;
+    constexpr int HOT_KEYS = 8, HOT_LIST = LINK_BLOCK_HOT;      // a list holds a whole block: no overflow (32 KB of LDS)
     __shared__ uint32_t hot_key[HOT ? HOT_KEYS : 1];               // slot + 1, 0 = free
     __shared__ uint32_t hot_cnt[HOT ? HOT_KEYS : 1];
     __shared__ uint32_t hot_list[HOT ? HOT_KEYS : 1][HOT ? HOT_LIST : 1];    // event index + 1
