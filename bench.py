@@ -50,6 +50,9 @@ def parse():
                     help="experiment: the engine's :fork-count-max (default: the job's count)")
     ap.add_argument("--join-max-wait", type=int, default=0,
                     help="experiment: every join carries this max-wait in seconds (store-nearest path)")
+    ap.add_argument("--zipf-frac", type=float, default=0.0,
+                    help="experiment: this fraction of the joins goes to the first 1000 barriers with Zipf(1.2) weights "
+                         "(many hot barriers at once; they never complete)")
     ap.add_argument("--route", action="store_true",
                     help="run the multi-GPU routing path (partition + all-to-all) even with one rank")
     return ap.parse_args()
@@ -191,6 +194,12 @@ def main():
         hot = torch.rand(nb * c, device=dev, generator=g) < a.hot_frac
         b_of = torch.where(hot, torch.zeros_like(b_of), b_of)
         p_of = torch.where(b_of == 0, p_of % (c - 1), p_of)
+    if a.zipf_frac > 0:
+        wz = 1.0 / torch.arange(1, 1001, dtype=torch.float64, device=dev) ** 1.2
+        pick = torch.multinomial(wz / wz.sum(), nb * c, replacement=True, generator=g)
+        sel = torch.rand(nb * c, device=dev, generator=g) < a.zipf_frac
+        b_of = torch.where(sel, pick, b_of)
+        p_of = torch.where(b_of < 1000, p_of % (c - 1), p_of)
     recs = torch.empty((nb * c, 4), dtype=torch.int64, device=dev)                 # dj_join_rec as 4 x i64
     recs[:, 0] = fps[b_of, 0]
     recs[:, 1] = fps[b_of, 1]
@@ -250,7 +259,7 @@ def main():
             if router is None:
                 # the hot key (barrier 0) is forked once and stays: re-forking it would clear what the engine has
                 # learnt about it, which is not what a barrier under a replay storm looks like
-                lo_f = 1 if (a.hot_frac > 0 and k >= steps_per_job) else 0
+                lo_f = (1 if a.hot_frac > 0 else 1000 if a.zipf_frac > 0 else 0) if k >= steps_per_job else 0
                 eng.fork_batch_dev(nb - lo_f, fork_recs[lo_f:], d_status)
             else:
                 h = pending_fork.pop(0) if pending_fork else router.start(fork_recs, None, nb)
@@ -279,7 +288,7 @@ def main():
                     pending.append(start_route(k + len(pending) + 1))
             if prefetch and s == steps_per_job - 1 and not pending_fork:
                 pending_fork.append(router.start(fork_recs, None, nb))
-        if a.hot_frac > 0:
+        if a.hot_frac > 0 or a.zipf_frac > 0:
             eng.sync()      # a host that reads each batch's statuses; also lets the engine see the previous
                             # batch's longest chain in time to pick the parallel hot-barrier kernels
 
@@ -357,7 +366,7 @@ def main():
         dom = max((k for k in kernels if kernels[k]["alg_bytes_per_launch"] > 0), key=lambda k: kernels[k]["total_ms"])
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf) and (nb, c, P, world) == (1 << 20, 8, 64, 1) and not routed and a.hot_frac == 0 and not a.max_message and not a.max_count and not a.join_max_wait:
+        if os.path.exists(tf) and (nb, c, P, world) == (1 << 20, 8, 64, 1) and not routed and a.hot_frac == 0 and not a.max_message and not a.max_count and not a.join_max_wait and not a.zipf_frac:
             # the counters were collected on this workload
             with open(tf) as f:
                 traffic = json.load(f).get(dom)

@@ -119,13 +119,16 @@ template <bool HOT>
 __global__ void __launch_bounds__(HOT ? LINK_BLOCK_HOT : LINK_BLOCK)
 join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t pitch, int32_t* status) {
     // Block-level pre-aggregation for barriers flagged hot: their events are chained inside the block
-    // through LDS and the block issues ONE exchange per hot barrier (a contended returning atomic
-    // costs ~60 ns, ten thousand of them on one word would serialise the whole pass).
-    constexpr int HOT_KEYS = 8, HOT_LIST = LINK_BLOCK_HOT;      // a list holds a whole block: no overflow (32 KB of LDS)
+    // through LDS and the block issues ONE exchange per hot barrier (a queued returning atomic costs
+    // ~40 ns, ten thousand of them on one word would serialise the whole pass).  Up to HOT_KEYS hot
+    // barriers per block: the events count themselves per barrier, a prefix sum gives every barrier its
+    // range in one shared list, the last entry of a range goes into the slot's chain word.
+    constexpr int HOT_KEYS = 64;
     __shared__ uint32_t hot_key[HOT ? HOT_KEYS : 1];               // slot + 1, 0 = free
     __shared__ uint32_t hot_cnt[HOT ? HOT_KEYS : 1];
-    __shared__ uint32_t hot_list[HOT ? HOT_KEYS : 1][HOT ? HOT_LIST : 1];    // event index + 1
+    __shared__ uint32_t hot_off[HOT ? HOT_KEYS : 1];
     __shared__ uint32_t hot_prev[HOT ? HOT_KEYS : 1];
+    __shared__ uint32_t hot_ev[HOT ? LINK_BLOCK_HOT : 1];          // event index + 1, grouped by barrier
     if constexpr (HOT) {
         if (threadIdx.x < HOT_KEYS) { hot_key[threadIdx.x] = 0; hot_cnt[threadIdx.x] = 0; }
         __syncthreads();
@@ -166,15 +169,14 @@ join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t 
             slot = (uint32_t)s;
             w.ev_slot[i] = slot;
             if (HOT && (info.y & META_HOT)) {
-                for (int j = 0; j < HOT_KEYS && agg_key < 0; ++j) {
+                // open addressing over the block's key table; a full table leaves the event to the direct exchange
+                uint32_t j = (slot * 2654435761u) >> 26;            // 6 bits: HOT_KEYS = 64
+                for (int probe = 0; probe < HOT_KEYS && agg_key < 0; ++probe, j = (j + 1) & (HOT_KEYS - 1)) {
                     const uint32_t k = atomicCAS(&hot_key[j], 0u, slot + 1);
                     if (k == 0 || k == slot + 1) {
-                        const uint32_t r = atomicAdd(&hot_cnt[j], 1u);
-                        if (r < HOT_LIST) {
-                            hot_list[j][r] = i + 1;
-                            agg_key = j; agg_rank = r; agg_pos = b.x; agg_mw = b.z;
-                        }
-                        break;       // list full: fall through to the direct exchange
+                        agg_key = (int)j;
+                        agg_rank = atomicAdd(&hot_cnt[j], 1u);
+                        agg_pos = b.x; agg_mw = b.z;
                     }
                 }
             }
@@ -186,14 +188,20 @@ join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t 
     }
     if constexpr (!HOT) return;
     __syncthreads();
-    if (threadIdx.x < HOT_KEYS && hot_cnt[threadIdx.x] != 0) {
-        const uint32_t m = hot_cnt[threadIdx.x] < HOT_LIST ? hot_cnt[threadIdx.x] : HOT_LIST;
-        hot_prev[threadIdx.x] = a_xchg(&t.slots[hot_key[threadIdx.x] - 1].chain, hot_list[threadIdx.x][m - 1]);
+    if (threadIdx.x < 64) {                                     // HOT_KEYS = 64: one wave scans the counts
+        const uint32_t c = hot_cnt[threadIdx.x];
+        hot_off[threadIdx.x] = wave_incl_scan(c) - c;
     }
     __syncthreads();
+    if (agg_key >= 0) hot_ev[hot_off[agg_key] + agg_rank] = i + 1;
+    __syncthreads();
+    if (threadIdx.x < HOT_KEYS && hot_cnt[threadIdx.x] != 0)
+        hot_prev[threadIdx.x] = a_xchg(&t.slots[hot_key[threadIdx.x] - 1].chain,
+                                       hot_ev[hot_off[threadIdx.x] + hot_cnt[threadIdx.x] - 1]);
+    __syncthreads();
     if (agg_key >= 0) {
-        // element r links to element r-1 of its block-local list, element 0 to the chain as it was
-        const uint32_t next = agg_rank == 0 ? hot_prev[agg_key] : hot_list[agg_key][agg_rank - 1];
+        // element r links to element r-1 of its barrier's range, element 0 to the chain as it was
+        const uint32_t next = agg_rank == 0 ? hot_prev[agg_key] : hot_ev[hot_off[agg_key] + agg_rank - 1];
         w.node[i] = node_pack(next, agg_pos, agg_mw);
     }
 }
