@@ -116,6 +116,22 @@ def test_hot_barrier_long_chains(oracle_lib, hot_mode):
         e.close()
 
 
+@pytest.mark.parametrize("hot_mode", [-1, 1])
+def test_many_hot_barriers_at_once(oracle_lib, hot_mode):
+    """Every barrier receives hundreds of events per batch, so all of them get flagged hot: more hot barriers
+    than one block of the link pass keeps lists for (64), which exercises the block-local lists, their
+    overflow into direct exchanges and the parallel long-chain kernels with many registered barriers."""
+    rng = np.random.default_rng(12)
+    nb = 90
+    ids = [f"mh{b}~t{b}" for b in range(nb)]
+    counts = rng.integers(2, 65, nb)
+    e, o, d = make_pair(oracle_lib, ids, 64, hot_mode=hot_mode, max_batch=1 << 17)
+    try:
+        run_oplog(d, rng, nb, counts, 64, rounds=6, batch=60000)
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("hot_mode", [-1, 0, 1])
 def test_large_counts_multiword_bitmaps(oracle_lib, hot_mode):
     rng = np.random.default_rng(3)

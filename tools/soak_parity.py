@@ -24,6 +24,8 @@ def main():
         ("small counts", 4000 * scale, (1, 9), 64, 20, 30000 * scale, dict(unknown=50), dict()),
         ("hot barrier", 2000 * scale, (2, 65), 64, 15, 40000 * scale, dict(hot=7), dict()),
         ("hot barrier, parallel kernels", 2000 * scale, (2, 65), 64, 15, 40000 * scale, dict(hot=7), dict(hot_mode=1)),
+        ("many hot barriers", 100, (2, 65), 64, 8, 60000 * scale, dict(), dict()),
+        ("many hot barriers, parallel kernels", 100, (2, 65), 64, 8, 60000 * scale, dict(), dict(hot_mode=1)),
         ("large counts", 300 * scale, (60, 1000), 64, 10, 60000 * scale, dict(hot=11), dict()),
         ("large counts, parallel kernels", 300 * scale, (60, 1000), 64, 10, 60000 * scale, dict(hot=11), dict(hot_mode=1)),
         ("variable lengths", 3000 * scale, (1, 20), 256, 12, 20000 * scale, dict(var_len=True), dict()),
