@@ -144,7 +144,8 @@ struct Work {
     unsigned long long* cx_atmin; // [CX_CAP] smallest now + 1000 * max-wait among the barrier's events
     uint32_t* cx_cnt;             // [CX_CAP] events of the barrier in this batch
     uint32_t* cx_T;               // [CX_CAP] first event index that answers COMPLETE, IDX_NONE = none
-    uint32_t* cx_hot;             // [CX_CAP] 1 when the barrier was already flagged hot before the batch
+    uint32_t* cx_hot;             // [CX_CAP] 0, or for a barrier flagged hot before the batch the pool entries per position
+                                  // (cx_hot_span: a power of two, 1 .. 128)
     uint32_t* cx_nq;              // [CX_CAP] 1 when the barrier was not in the primary queue before the batch
     uint32_t cx_on;               // 1: this batch runs the parallel hot-barrier kernels
 };
@@ -152,9 +153,18 @@ enum { C_COMPLEX = 1, C_MAXCHAIN = 2, C_CXPOOL = 3, C_COUNT = 8 };
 constexpr uint32_t CX_CAP = 65536;     // barriers with long chains per batch handled by the parallel path
 constexpr uint32_t CX_HASH = 262144;   // power of two, >= 2 * CX_CAP
 constexpr uint32_t CX_HOT_STRIDE = 8;  // pool entries per table line (64 bytes)
-constexpr uint32_t CX_HOT_REPL = 16;   // a barrier flagged hot gets this many lines per position: its events spread their
-                                       // atomics over them by wave, the finalize pass folds them into the first
-constexpr uint32_t CX_HOT_SPAN = CX_HOT_STRIDE * CX_HOT_REPL;   // pool entries per position of a hot barrier
+// A barrier flagged hot spreads every position over several 64-byte lines (its events pick one by wave, the
+// finalize pass folds them into the first): thousands of atomics on ONE line would queue up.  The fewer
+// positions a barrier has, the more events each of them takes, the more lines it gets: about 2048 pool
+// entries (16 KB) per hot barrier whatever its count.  Below 8 entries per position there is one copy and
+// positions share lines.
+__host__ __device__ inline uint32_t cx_hot_span(uint32_t count) {
+    uint32_t p2 = 1;
+    while (p2 < count) p2 <<= 1;
+    const uint32_t span = 2048u / p2;
+    return span > 128u ? 128u : span < 1u ? 1u : span;
+}
+__host__ __device__ inline uint32_t cx_span_replicas(uint32_t span) { return span >= 2 * CX_HOT_STRIDE ? span / CX_HOT_STRIDE : 1u; }
 constexpr uint32_t CX_POOL = 1u << 24; // positions of all of them together (the rest takes the serial kernel)
 constexpr uint32_t IDX_NONE = 0xFFFFFFFFu;
 // sweep scratch: S_CURSOR packs both output cursors so a block takes its output range with one

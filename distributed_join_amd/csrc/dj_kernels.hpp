@@ -447,7 +447,8 @@ __global__ void __launch_bounds__(256) cx_init_kernel(Table t, Work w) {
         }
         // a barrier already known to be hot spreads its positions over one 64-byte line each: thousands
         // of atomics on ONE line would queue up
-        const uint32_t share = hot ? count * CX_HOT_SPAN : count;
+        const uint32_t span = hot ? cx_hot_span(count) : 0u;
+        const uint32_t share = hot ? count * span : count;
         const uint32_t incl = wave_incl_scan(share);
         const uint32_t total = __shfl(incl, 63);
         uint32_t base = 0;
@@ -462,7 +463,7 @@ __global__ void __launch_bounds__(256) cx_init_kernel(Table t, Work w) {
                 if (off != IDX_NONE) {
                     w.cx_atmin[c] = NQ;
                     w.cx_cnt[c] = 0;
-                    w.cx_hot[c] = hot;
+                    w.cx_hot[c] = span;
                     for (uint32_t h = cx_hash(slab);; h = (h + 1) & (CX_HASH - 1)) {
                         if (atomicCAS(&w.cx_keys[h], 0u, slab) == 0u) { w.cx_val[h] = c; break; }
                     }
@@ -493,9 +494,10 @@ __global__ void __launch_bounds__(256) cx_scan_kernel(Work w, uint32_t n, uint64
             if (d != NODST) c = cx_lookup(w, (uint32_t)d);
             if (c != IDX_NONE) {
                 const uint64_t x = w.node[i];
-                // first and last index share 8 bytes; a hot barrier's position has CX_HOT_REPL lines, picked by wave
-                key = w.cx_hot[c] ? w.cx_off[c] + node_pos(x) * CX_HOT_SPAN + (uint32_t)((base >> 6) & (CX_HOT_REPL - 1)) * CX_HOT_STRIDE
-                                  : w.cx_off[c] + node_pos(x);
+                // first and last index share 8 bytes; a hot barrier's position may have several lines, picked by wave
+                const uint32_t span = w.cx_hot[c];
+                key = span ? w.cx_off[c] + node_pos(x) * span + (uint32_t)((base >> 6) & (cx_span_replicas(span) - 1)) * CX_HOT_STRIDE
+                           : w.cx_off[c] + node_pos(x);
                 mw = node_mw(x);
             }
         }
@@ -539,8 +541,9 @@ __global__ void __launch_bounds__(64) cx_finalize_kernel(Table t, Work w, uint64
         Slot* sl = &t.slots[s];
         const uint32_t count = sl->count, slab = sl->slab;
         const uint64_t bits_pre = sl->bits;
-        const bool hot = w.cx_hot[c] != 0;
-        const uint32_t pstride = hot ? CX_HOT_SPAN : 1u;
+        const uint32_t span = w.cx_hot[c];
+        const bool hot = span != 0;
+        const uint32_t pstride = hot ? span : 1u, replicas = hot ? cx_span_replicas(span) : 1u;
         uint32_t t_complete = 0, n_new = 0;
         uint64_t bits0 = bits_pre;
         const uint32_t words = (count + 63) >> 6;
@@ -551,7 +554,7 @@ __global__ void __launch_bounds__(64) cx_finalize_kernel(Table t, Work w, uint64
             if (p < count) {
                 uint2 mm = w.cx_mm[off + p * pstride];
                 if (hot) {      // fold the position's lines into the first: the copy pass reads the last index there
-                    for (uint32_t r = 1; r < CX_HOT_REPL; ++r) {
+                    for (uint32_t r = 1; r < replicas; ++r) {
                         const uint2 o = w.cx_mm[off + p * pstride + r * CX_HOT_STRIDE];
                         if (o.x < mm.x) mm.x = o.x;
                         if (o.y > mm.y) mm.y = o.y;
@@ -633,7 +636,7 @@ __global__ void __launch_bounds__(256) join_copy_kernel(Table t, Work w, const d
                     if (T != IDX_NONE && i >= T) status[i] = DJ_JOIN_COMPLETE;
                     else if (b.z && w.cx_nq[c]) status[i] = DJ_JOIN_NEAREST_NOT_QUEUED;
                 }
-                if (w.cx_mm[w.cx_off[c] + b.x * (w.cx_hot[c] ? CX_HOT_SPAN : 1u)].y != (uint32_t)i + 1) continue;   // a later event of the batch wrote this position
+                if (w.cx_mm[w.cx_off[c] + b.x * (w.cx_hot[c] ? w.cx_hot[c] : 1u)].y != (uint32_t)i + 1) continue;   // a later event of the batch wrote this position
             }
         }
         if (j0 == 0 && (d & DST_PM)) slab_posmeta(t, slab, k)[b.x] = make_uint2(b.y, b.z);
@@ -686,7 +689,7 @@ __global__ void __launch_bounds__(256) join_copy_long_kernel(Table t, Work w, co
                         if (T != IDX_NONE && i >= T) status[i] = DJ_JOIN_COMPLETE;
                         else if (b.z && w.cx_nq[c]) status[i] = DJ_JOIN_NEAREST_NOT_QUEUED;
                     }
-                    if (w.cx_mm[w.cx_off[c] + b.x * (w.cx_hot[c] ? CX_HOT_SPAN : 1u)].y != (uint32_t)i + 1) live = false;
+                    if (w.cx_mm[w.cx_off[c] + b.x * (w.cx_hot[c] ? w.cx_hot[c] : 1u)].y != (uint32_t)i + 1) live = false;
                 }
             }
         }
