@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
         Slot* sl = &t.slots[s];
         const uint32_t count = sl->count, slab = sl->slab;
         const uint32_t head = sl->chain;
-        for (uint32_t p = lane; p < 1024; p += 64) { fmin[p] = IDX_NONE; fmax[p] = 0; }
+        for (uint32_t p = lane; p < count; p += 64) { fmin[p] = IDX_NONE; fmax[p] = 0; }    // count <= 999
         __syncthreads();
         uint64_t at_min = NQ;      // smallest now + 1000*max-wait over the batch's waiting events
         if (lane == 0) {
