@@ -477,10 +477,10 @@ extern "C" int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs
     const volatile unsigned int* hint = e->h_maxchain;
     // The serial kernel walks one chain per wave on 2048 blocks, about 0.6 us per link: its time grows with
     // (rounds of 2048 barriers) x (longest chain).  The parallel kernels cost about 80 us whatever the chains
-    // look like (measured break-even: 200 barriers x 128 events; 500 x 200 and 8192 x 128 go parallel,
-    // 2000 x 50 and 8000 x 12 stay serial).
+    // look like (measured: 100 barriers x 250 events and 500 x 200 break even, 8192 x 128 and anything longer
+    // than the serial kernel's 256-entry chain copy go parallel, 2000 x 50 and 8000 x 12 stay serial).
     const unsigned int rounds = hint[0] / 2048 + 1;
-    e->w.cx_on = e->cx_force >= 0 ? (uint32_t)e->cx_force : ((uint64_t)rounds * hint[1] > 160 ? 1u : 0u);
+    e->w.cx_on = e->cx_force >= 0 ? (uint32_t)e->cx_force : ((uint64_t)rounds * hint[1] > 256 ? 1u : 0u);
     if (e->w.cx_on)
         LAUNCH(e, DJ_PROF_JOIN_LINK, (join_link_kernel<true><<<grid_for(n, LINK_BLOCK_HOT), LINK_BLOCK_HOT, 0, e->stream>>>(e->t, e->w, d_recs, n, pitch, d_status)));
     else

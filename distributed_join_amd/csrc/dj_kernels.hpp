@@ -325,6 +325,11 @@ __global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint
 __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work w, uint64_t now, int32_t* status) {
     __shared__ uint32_t fmin[1024];
     __shared__ uint32_t fmax[1024];
+    // the chain as lane 0 found it (link words and event indices): the answers are then written by all lanes
+    constexpr uint32_t CHAIN_LDS = 256;
+    __shared__ uint64_t cn[CHAIN_LDS];
+    __shared__ uint32_t ci[CHAIN_LDS];
+    __shared__ uint32_t s_len;
     const uint32_t lane = threadIdx.x;
     const uint32_t nc = w.counters[C_COMPLEX];
     for (uint32_t c = blockIdx.x; c < nc; c += gridDim.x) {
@@ -343,8 +348,10 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
                 const uint32_t i = cur - 1, pos = node_pos(x);
                 if (i < fmin[pos]) fmin[pos] = i;
                 if (i + 1 > fmax[pos]) fmax[pos] = i + 1;
+                if (len < CHAIN_LDS) { cn[len] = x; ci[len] = i; }
                 cur = node_next(x);
             }
+            s_len = len;
             a_max(&w.counters[C_MAXCHAIN], len);    // the host picks the parallel kernels for the next batch from this
             if (len >= 256) sl->meta |= META_HOT; else sl->meta &= ~META_HOT;
         }
@@ -375,28 +382,45 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
             if (o > t_complete) t_complete = o;
         }
         bits0 = __shfl(bits0, 0);
-        if (lane == 0) {
-            const uint32_t arrived_pre = count > 64 ? (uint32_t)sl->bits : (uint32_t)__popcll(sl->bits);
-            const uint32_t arrived = arrived_pre + n_new;
-            // first event index that answers COMPLETE
-            uint32_t T = IDX_NONE;
-            if (arrived_pre == count) T = 0;
-            else if (arrived == count) T = t_complete;
-            const uint64_t pa_pre = q_primary_at(t.q[s]);
+        const uint64_t bits_pre = sl->bits;
+        const uint32_t arrived_pre = count > 64 ? (uint32_t)bits_pre : (uint32_t)__popcll(bits_pre);
+        const uint32_t arrived = arrived_pre + n_new;
+        // first event index that answers COMPLETE
+        uint32_t T = IDX_NONE;
+        if (arrived_pre == count) T = 0;
+        else if (arrived == count) T = t_complete;
+        const uint64_t pa_pre = q_primary_at(t.q[s]);
+        const uint32_t len = s_len;
+        // one event's answer; returns its queue date when it waits with a max-wait, else NQ
+        auto answer = [&](uint64_t x, uint32_t i) -> uint64_t {
+            const uint32_t pos = node_pos(x), mw = node_mw(x);
+            int32_t st = DJ_JOIN_WAITING;
+            uint64_t at = NQ;
+            if (i >= T && T != IDX_NONE) st = DJ_JOIN_COMPLETE;
+            else if (mw && pa_pre == NQ) st = DJ_JOIN_NEAREST_NOT_QUEUED;
+            else if (mw) at = now + 1000ull * mw;
+            if (st != DJ_JOIN_WAITING) status[i] = st;
+            if (fmax[pos] != i + 1) w.dst[i] = NODST;
+            return at;
+        };
+        if (len <= CHAIN_LDS) {                   // all lanes, from the copy in LDS
+            for (uint32_t k = lane; k < len; k += 64) {
+                const uint64_t at = answer(cn[k], ci[k]);
+                if (at < at_min) at_min = at;
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint64_t o = ((uint64_t)__shfl_xor((uint32_t)(at_min >> 32), off) << 32) | __shfl_xor((uint32_t)at_min, off);
+                if (o < at_min) at_min = o;
+            }
+        } else if (lane == 0) {                   // longer than the copy: walk again
             for (uint32_t cur = head; cur != 0;) {
                 const uint64_t x = w.node[cur - 1];
-                const uint32_t i = cur - 1, pos = node_pos(x), mw = node_mw(x);
-                int32_t st;
-                if (i >= T && T != IDX_NONE) st = DJ_JOIN_COMPLETE;
-                else if (mw && pa_pre == NQ) st = DJ_JOIN_NEAREST_NOT_QUEUED;
-                else {
-                    st = DJ_JOIN_WAITING;
-                    if (mw) { uint64_t at = now + 1000ull * mw; if (at < at_min) at_min = at; }
-                }
-                if (st != DJ_JOIN_WAITING) status[i] = st;
-                if (fmax[pos] != i + 1) w.dst[i] = NODST;
+                const uint64_t at = answer(x, cur - 1);
+                if (at < at_min) at_min = at;
                 cur = node_next(x);
             }
+        }
+        if (lane == 0) {
             sl->bits = count > 64 ? (uint64_t)arrived : bits0;
             sl->join_ts = now;
             sl->chain = 0;
