@@ -629,6 +629,7 @@ __device__ inline uint32_t node_mw(uint64_t x) { return (uint32_t)(x >> 35); }
 // DST_PM the copy pass needs nothing else from the event's record.
 constexpr uint64_t DST_FULL = 1ull << 46;   // the message fills its row exactly
 constexpr uint64_t DST_OVF = 1ull << 47;    // the barrier holds (or held) long messages: the position's old length matters
+constexpr uint64_t DST_CX = 1ull << 48;     // set by cx_scan: the event's barrier is registered with the parallel long-chain kernels
 constexpr uint64_t DST_PM = 1ull << 62;     // also write the position's {len, max_wait}
 __device__ inline uint64_t dst_pack(uint32_t slab, uint32_t count, uint32_t pos) {
     return (uint64_t)slab | ((uint64_t)class_of(count) << 32) | ((uint64_t)pos << 36);

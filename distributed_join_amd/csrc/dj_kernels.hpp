@@ -517,6 +517,7 @@ __global__ void __launch_bounds__(256) cx_scan_kernel(Work w, uint32_t n, uint64
             const uint64_t d = w.dst[i];
             if (d != NODST) c = cx_lookup(w, (uint32_t)d);
             if (c != IDX_NONE) {
+                w.dst[i] = d | DST_CX;             // the copy pass looks the barrier up again only for these
                 const uint64_t x = w.node[i];
                 // first and last index share 8 bytes; a hot barrier's position may have several lines, picked by wave
                 const uint32_t span = w.cx_hot[c];
@@ -650,8 +651,9 @@ __global__ void __launch_bounds__(256) join_copy_kernel(Table t, Work w, const d
         const uint32_t slab = (uint32_t)d, k = dst_class(d);
         // position and "full row" travel in d; the record is read only when more is needed
         uint4 b = make_uint4(dst_pos(d), t.stride, 0, 0);                    // position, len, max_wait
-        if (hot || (d & DST_PM) || !(d & DST_FULL)) b = reinterpret_cast<const uint4*>(recs)[2 * i + 1];
-        if (hot) {
+        const bool cx = hot && (d & DST_CX);
+        if (cx || (d & DST_PM) || !(d & DST_FULL)) b = reinterpret_cast<const uint4*>(recs)[2 * i + 1];
+        if (cx) {
             // an event of a hot barrier gets its answer here, from the tables of the cx_* kernels
             const uint32_t c = cx_lookup(w, slab);
             if (c != IDX_NONE) {
@@ -704,8 +706,9 @@ __global__ void __launch_bounds__(256) join_copy_long_kernel(Table t, Work w, co
         const uint32_t slab = (uint32_t)d, k = live ? dst_class(d) : 0;
         if (live) {
             b = make_uint4(dst_pos(d), t.stride, 0, 0);            // position, len, max_wait
-            if (hot || (d & DST_PM) || !(d & DST_FULL)) b = reinterpret_cast<const uint4*>(recs)[2 * i + 1];
-            if (hot) {
+            const bool cx = hot && (d & DST_CX);
+            if (cx || (d & DST_PM) || !(d & DST_FULL)) b = reinterpret_cast<const uint4*>(recs)[2 * i + 1];
+            if (cx) {
                 const uint32_t c = cx_lookup(w, slab);
                 if (c != IDX_NONE) {
                     const uint32_t T = w.cx_T[c];
