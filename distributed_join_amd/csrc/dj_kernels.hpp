@@ -352,37 +352,34 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
                 cur = node_next(x);
             }
             s_len = len;
-            a_max(&w.counters[C_MAXCHAIN], len);    // the host picks the parallel kernels for the next batch from this
+            // the host picks the parallel kernels for the next batch from this; thousands of barriers report, so
+            // the atomic (they queue up on the one word) is only issued by a chain longer than the longest so far
+            if (len > a_load(&w.counters[C_MAXCHAIN])) a_max(&w.counters[C_MAXCHAIN], len);
             if (len >= 256) sl->meta |= META_HOT; else sl->meta &= ~META_HOT;
         }
         __syncthreads();
-        // newly present positions, word by word (lane j owns words j, j+64, ...)
+        // newly present positions: 64 positions (one bitmap word) per step, one lane per position
         uint32_t t_complete = 0, n_new = 0;
         const uint32_t words = (count + 63) >> 6;
-        uint64_t bits0 = sl->bits;
-        for (uint32_t wd = lane; wd < words; wd += 64) {
-            uint64_t word = count > 64 ? slab_bitmap(t, slab)[wd] : bits0;
-            uint64_t add = 0;
-            for (uint32_t b = 0; b < 64 && wd * 64 + b < count; ++b) {
-                const uint32_t p = wd * 64 + b;
-                if (fmin[p] != IDX_NONE && !((word >> b) & 1)) {
-                    add |= 1ull << b;
-                    ++n_new;
-                    if (fmin[p] > t_complete) t_complete = fmin[p];
-                }
-            }
+        const uint64_t bits_pre = sl->bits;
+        uint64_t bits0 = bits_pre;
+        for (uint32_t wd = 0; wd < words; ++wd) {
+            const uint32_t p = wd * 64 + lane;
+            const uint64_t word = count > 64 ? slab_bitmap(t, slab)[wd] : bits_pre;
+            const uint32_t f = p < count ? fmin[p] : IDX_NONE;
+            const bool fresh = f != IDX_NONE && !((word >> lane) & 1);
+            if (fresh && f > t_complete) t_complete = f;
+            const uint64_t add = __ballot(fresh);
+            n_new += (uint32_t)__popcll(add);          // the same in every lane
             if (add) {
-                if (count > 64) slab_bitmap(t, slab)[wd] = word | add;
+                if (count > 64) { if (lane == 0) slab_bitmap(t, slab)[wd] = word | add; }
                 else bits0 = word | add;
             }
         }
         for (int off = 32; off > 0; off >>= 1) {
-            n_new += __shfl_xor(n_new, off);
-            uint32_t o = __shfl_xor(t_complete, off);
+            const uint32_t o = __shfl_xor(t_complete, off);
             if (o > t_complete) t_complete = o;
         }
-        bits0 = __shfl(bits0, 0);
-        const uint64_t bits_pre = sl->bits;
         const uint32_t arrived_pre = count > 64 ? (uint32_t)bits_pre : (uint32_t)__popcll(bits_pre);
         const uint32_t arrived = arrived_pre + n_new;
         // first event index that answers COMPLETE
