@@ -547,7 +547,29 @@ __global__ void __launch_bounds__(256) cx_scan_kernel(Work w, uint32_t n, uint64
             }
             todo &= ~grp;
         }
-        if (live && mw) atomicMin(&w.cx_atmin[c], (unsigned long long)(now + 1000ull * mw));
+        // earliest queue date among the barrier's waiting events.  A hot barrier's events would queue up on the one
+        // word: its lanes reduce inside the wave first, and only an earlier date than the one already there is
+        // worth an atomic (after the first few waves almost none is).
+        if (live && !hot && mw) {
+            const unsigned long long at = now + 1000ull * mw;
+            if (at < a_load(&w.cx_atmin[c])) atomicMin(&w.cx_atmin[c], at);
+        }
+        uint64_t todo_mw = __ballot(hot && mw);
+        while (todo_mw) {
+            const int l0 = __ffsll((unsigned long long)todo_mw) - 1;
+            const uint32_t c0 = __shfl(c, l0);
+            const bool mine = hot && mw && c == c0;
+            uint32_t m = mine ? mw : 0xFFFFFFFFu;
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t o = __shfl_xor(m, off);
+                if (o < m) m = o;
+            }
+            if ((int)lane == l0) {
+                const unsigned long long at = now + 1000ull * m;
+                if (at < a_load(&w.cx_atmin[c0])) atomicMin(&w.cx_atmin[c0], at);
+            }
+            todo_mw &= ~__ballot(mine);
+        }
     }
 }
 
