@@ -777,7 +777,7 @@ __global__ void __launch_bounds__(256) join_copy_long_kernel(Table t, Work w, co
                 dj_long_ref ref;
                 ref.unit = unit_new; ref.size_class = k_new; ref.len = b.y; ref.zero = 0;
                 *reinterpret_cast<dj_long_ref*>(row) = ref;
-                atomicOr(&t.slots[w.ev_slot[i]].meta, META_OVF);
+                if (!(d & DST_OVF)) atomicOr(&t.slots[w.ev_slot[i]].meta, META_OVF);   // not flagged yet at link time
             }
         }
         if (live && !new_long) {
