@@ -117,6 +117,8 @@ struct Table {
     unsigned int* oring_tail_snap;    // tails before the current join batch's copy pass: pops stop here
     uint32_t max_message;             // longest message accepted, >= stride
     uint32_t stride;
+    uint32_t fork_pmd;                // 1: barriers are forked with META_PMD set (recent joins were mostly not full rows
+                                      // without max-wait: the flag would be set by their first join anyway, with an atomic)
     uint32_t max_count;
     uint32_t max_retry_publish, max_retry_timeout_publish;
     uint64_t check_publish_delay_ms;
@@ -133,7 +135,8 @@ struct Work {
     unsigned int* counters;       // C_* below, bank of the current join batch
     unsigned int* counters_next;  // the other bank: zeroed by the current batch for the next one
     unsigned int* hint;           // pinned HOST memory: [0] barriers with long chains, [1] longest chain of the latest
-                                  // join batch, written by its last kernel (the host reads them without waiting)
+                                  // join batch, written by its last kernel (the host reads them without waiting);
+                                  // [4..7] how many of the batch's first 4 x 64 events store a {len, max-wait} word
     unsigned long long* sweep;    // S_* below, bank of the current sweep
     unsigned long long* sweep_next;
     // hot-barrier path (barriers with long chains), see the cx_* kernels

@@ -249,7 +249,7 @@ static int create_impl(dj_engine* e) {
     ALLOC(e, w.cx_hot, CX_CAP * 4);
     w.cx_on = 0;
     HIP_TRY(e, hipHostMalloc((void**)&e->h_maxchain, 64, hipHostMallocDefault));
-    e->h_maxchain[0] = e->h_maxchain[1] = 0;
+    memset(e->h_maxchain, 0, 64);
     w.hint = e->h_maxchain;       // hipHostMalloc memory is addressable from the device
     ALLOC(e, e->d_sweep, 2 * S_COUNT * 8);
     HIP_TRY(e, hipMemsetAsync(e->d_sweep, 0, 2 * S_COUNT * 8, e->stream));
@@ -437,6 +437,10 @@ extern "C" int dj_fork_batch(dj_engine* e, uint32_t n, const dj_fork_rec* d_recs
         }
     } else {
         (void)compact_finish(e, false);
+    }
+    {   // of the latest join batch's first 256 events, did most store a {len, max-wait} word?
+        const volatile unsigned int* hint = e->h_maxchain;
+        e->t.fork_pmd = hint[4] + hint[5] + hint[6] + hint[7] >= 128 ? 1u : 0u;
     }
     e->used_upper += n;
     e->claimed_since_compact += n;

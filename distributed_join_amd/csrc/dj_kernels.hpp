@@ -88,9 +88,11 @@ __global__ void __launch_bounds__(FORK_APPLY_BLOCK) fork_apply_kernel(Table t, W
         uint64_t* bm = slab_bitmap(t, slab);
         for (uint32_t j = 0; j < (class_positions(k_new) >> 6); ++j) bm[j] = 0;
     }
-    fill_posmeta_default(t, slab, k_new);                 // and no position holds a long message
+    // pre-filled words are what a barrier without META_PMD relies on; with long messages enabled the words of
+    // absent positions are read as well (none may look like a long message)
+    if (!t.fork_pmd || long_on) fill_posmeta_default(t, slab, k_new);
     sl->count = r.count;                                  // SET <id>:metadata
-    sl->meta = meta_pack(true, RETRY_NIL, RETRY_NIL);
+    sl->meta = meta_pack(true, RETRY_NIL, RETRY_NIL) | (t.fork_pmd ? META_PMD : 0u);
     sl->slab = slab;
     sl->chain = 0;
     sl->deadline = r.deadline_ms;
@@ -135,6 +137,7 @@ join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t 
     }
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t slot = 0;
+    bool stores_meta = false;      // this event writes its position's {len, max-wait} word
     int agg_key = -1;
     uint32_t agg_rank = 0, agg_pos = 0, agg_mw = 0;
     if (i < n) {
@@ -163,6 +166,7 @@ join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t 
             // {len, max_wait} of a position is stored only when it differs from a full row without max-wait,
             // or when the barrier has seen such a position before (META_PMD, sticky until the next fork)
             const bool pm = (info.y & META_PMD) || b.y != t.stride || b.z != 0;
+            stores_meta = pm;
             w.dst[i] = dst_pack(info.z, info.x, b.x) | (pm ? DST_PM : 0ull) | (b.y == t.stride ? DST_FULL : 0ull) |
                        ((info.y & META_OVF) ? DST_OVF : 0ull);
             if (pm && !(info.y & META_PMD)) atomicOr(&t.slots[s].meta, META_PMD);
@@ -185,6 +189,11 @@ join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t 
                 w.node[i] = node_pack(prev, b.x, b.z);
             }
         }
+    }
+    // a sample for the host: how ragged is the traffic (it decides how the next barriers are forked)
+    if (blockIdx.x == 0 && threadIdx.x < 256) {
+        const uint64_t m = __ballot(stores_meta);
+        if ((threadIdx.x & 63) == 0) w.hint[4 + (threadIdx.x >> 6)] = (unsigned int)__popcll(m);
     }
     if constexpr (!HOT) return;
     __syncthreads();
