@@ -762,3 +762,100 @@ def test_config5_large_properties():
         assert e.stats()["live"] == 0
     finally:
         e.close()
+
+
+def test_config4_one_rank_full_size_properties():
+    """BASELINE config #4 from the point of view of one of its eight GPUs, at full size: 12.5 M barriers of
+    count 16 with 256-byte messages, 200 M joins in uniformly shuffled order, batches of 4 M.  Checked from the
+    generator's arithmetic: every barrier fires exactly once, COMPLETE, in the batch that brings its last
+    position, with every byte where the generator put it.  (Routing is covered at a smaller size by
+    test_config4_one_rank_share_scaled; here the events are already the rank's own.)"""
+    import time
+    import torch
+    t_start = time.time()
+    nb, c, P, batch = 12_500_000, 16, 256, 1 << 22
+    ids = [f"j{b % 1000:x}~t{b:x}" for b in range(nb)]
+    fps_np = capi.fingerprint_many(ids).view(np.int64)
+    del ids
+    e = _engine(capacity_barriers=nb, arena_bytes=nb * (c * P + 192) + (256 << 20), max_count=c, payload_stride=P,
+                max_batch=batch)
+    dev = e.device
+    try:
+        g = torch.Generator(device=dev)
+        g.manual_seed(4)
+        fps = torch.from_numpy(fps_np).to(dev)
+        n_events = nb * c
+        ev_cell = torch.randperm(n_events, device=dev, generator=g)          # cell = barrier * c + position
+        n_batches = (n_events + batch - 1) // batch
+        ev_batch = torch.arange(n_events, device=dev) // batch
+        fire_batch = torch.zeros(nb, dtype=torch.int64, device=dev).scatter_reduce(0, ev_cell // c, ev_batch, "amax")
+        del ev_batch
+        d_status = torch.empty(batch, dtype=torch.int32, device=dev)
+        frecs = torch.empty((batch, 4), dtype=torch.int64, device=dev)
+        for lo in range(0, nb, batch):                                       # forks in pieces of one batch
+            m = min(batch, nb - lo)
+            frecs[:m, 0], frecs[:m, 1], frecs[:m, 2], frecs[:m, 3] = fps[lo:lo + m, 0], fps[lo:lo + m, 1], c, T0 + 3_600_000
+            torch.cuda.synchronize()
+            e.fork_batch_dev(m, frecs, d_status)
+            e.sync()
+            assert bool((d_status[:m] == capi.DJ_FORK_CREATED).all())
+        del frecs
+        order = torch.argsort(fps[:, 0])
+        sorted_lo = fps[order, 0].contiguous()
+        cap_c, cap_p = 1 << 21, 1 << 24
+        d_conts = torch.empty((cap_c, 8), dtype=torch.int64, device=dev)
+        d_lens = torch.empty(cap_p, dtype=torch.int32, device=dev)
+        d_pay = torch.empty((cap_p, P), dtype=torch.uint8, device=dev)
+        d_res = torch.empty(16, dtype=torch.uint8, device=dev)
+        d_ack = torch.empty(cap_c, dtype=torch.int32, device=dev)
+        fired = torch.zeros(nb, dtype=torch.int32, device=dev)
+        n_complete_status = 0
+        print(f"\n  {nb} barriers forked, {n_events} events in {n_batches} batches, {time.time() - t_start:.1f} s", flush=True)
+        for k in range(n_batches):
+            now = T0 + 2 * (k + 1)
+            cell = ev_cell[k * batch:(k + 1) * batch]
+            n = len(cell)
+            jb, jp = cell // c, cell % c
+            recs = torch.empty((n, 4), dtype=torch.int64, device=dev)
+            recs[:, 0], recs[:, 1], recs[:, 2], recs[:, 3] = fps[jb, 0], fps[jb, 1], jp | (P << 32), 0
+            pay = _payload_bytes_t(torch, jb, jp, P)
+            torch.cuda.synchronize()
+            e.join_batch_dev(n, recs, pay, P, now, d_status)
+            e.sync()
+            st = d_status[:n]
+            assert bool(((st == capi.DJ_JOIN_WAITING) | (st == capi.DJ_JOIN_COMPLETE)).all())
+            n_complete_status += int((st == capi.DJ_JOIN_COMPLETE).sum())
+            del recs, pay
+            while True:
+                res = np.zeros(1, dtype=capi.SWEEP_RESULT)
+                e.sweep_dev(now, cap_c, cap_p, d_conts, d_lens, None, d_pay, d_res, res)
+                rows = int(res[0]["n_conts"])
+                if rows:
+                    cc = d_conts[:rows]
+                    void = ((cc[:, 4] >> 32) & capi.DJ_CONT_VOID) != 0
+                    cc = cc[~void].contiguous()
+                    m = len(cc)
+                    at = torch.searchsorted(sorted_lo, cc[:, 0].contiguous()).clamp_(max=nb - 1)
+                    b = order[at]
+                    assert bool((fps[b, 0] == cc[:, 0]).all()) and bool((fps[b, 1] == cc[:, 1]).all())
+                    fired.index_add_(0, b, torch.ones(m, dtype=torch.int32, device=dev))
+                    assert bool((fire_batch[b] == k).all()), "a barrier fired in another batch than the one that completed it"
+                    assert bool((cc[:, 4] == c).all())                       # count 16, no flags
+                    row = (cc[:, 6][:, None] + torch.arange(c, device=dev)[None, :]).reshape(-1)
+                    assert bool((d_lens[row] == P).all())
+                    for lo in range(0, m, 1 << 16):                           # in pieces: 256-byte rows
+                        bb = b[lo:lo + (1 << 16)]
+                        want = _payload_bytes_t(torch, bb.repeat_interleave(c), torch.arange(c, device=dev).repeat(len(bb)), P)
+                        assert bool((d_pay[row[lo * c:(lo + (1 << 16)) * c]] == want).all()), "a gathered byte differs from the generator"
+                    torch.cuda.synchronize()
+                    e.ack_batch_dev(rows, None, d_conts, None, now, d_ack)
+                    e.sync()
+                    assert bool((d_ack[:rows][~void] == capi.DJ_ACK_DONE).all())
+                if not res[0]["more"]:
+                    break
+        print(f"  all batches checked, {time.time() - t_start:.1f} s", flush=True)
+        assert bool((fired == 1).all())
+        assert n_complete_status == nb
+        assert e.stats()["live"] == 0
+    finally:
+        e.close()
