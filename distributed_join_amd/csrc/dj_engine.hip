@@ -38,7 +38,7 @@ struct dj_engine {
     std::recursive_mutex mu;     // entry points serialise themselves: callers may share an engine between threads
     Slot* slots_alt;             // second table for dj_compact (always all-empty between calls)
     uint64_t* q_alt;
-    int cx_force;                // -1: automatic, 0 / 1: force the serial / parallel hot-barrier kernels (tests)
+    int cx_force;                // -1: automatic; else bit 0: parallel hot-barrier kernels, bit 1: wide register replay (tests)
     unsigned int* h_maxchain;    // pinned: longest chain of the previous join batch (picks the hot-barrier kernels)
     uint64_t used_upper;         // upper bound of non-empty slots (live + tombstones) since the last compaction
     // an automatic compaction does not wait for its live count: it arrives in pinned memory
@@ -322,7 +322,7 @@ extern "C" int dj_get_config(const dj_engine* e, dj_config* out) {
 }
 
 extern "C" int dj_set_hot_path(dj_engine* e, int mode) {
-    if (!e || mode < -1 || mode > 1) return DJ_E_INVALID;
+    if (!e || mode < -1 || mode > 3) return DJ_E_INVALID;
     std::lock_guard<std::recursive_mutex> guard(e->mu);
     e->cx_force = mode;
     return DJ_OK;
@@ -462,6 +462,8 @@ static void launch_join_copy(dj_engine* e, uint32_t n, const dj_join_rec* recs, 
         join_copy_kernel<G><<<(uint32_t)blocks, 256, 0, e->stream>>>(e->t, e->w, recs, payloads, pitch, n, status);
 }
 
+constexpr unsigned int WIDE_ON = 2048;   // barriers with 9..16 events in a batch from which the wide replay pays
+
 extern "C" int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs, const uint8_t* d_payloads,
                              uint64_t pitch, uint64_t now_ms, int32_t* d_status) {
     if (!e) return DJ_E_INVALID;
@@ -484,12 +486,18 @@ extern "C" int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs
     // look like (measured: 100 barriers x 250 events and 500 x 200 break even, 8192 x 128 and anything longer
     // than the serial kernel's 256-entry chain copy go parallel, 2000 x 50 and 8000 x 12 stay serial).
     const unsigned int rounds = hint[0] / 2048 + 1;
-    e->w.cx_on = e->cx_force >= 0 ? (uint32_t)e->cx_force : ((uint64_t)rounds * hint[1] > 256 ? 1u : 0u);
+    e->w.cx_on = e->cx_force >= 0 ? (uint32_t)(e->cx_force & 1) : ((uint64_t)rounds * hint[1] > 256 ? 1u : 0u);
     if (e->w.cx_on)
         LAUNCH(e, DJ_PROF_JOIN_LINK, (join_link_kernel<true><<<grid_for(n, LINK_BLOCK_HOT), LINK_BLOCK_HOT, 0, e->stream>>>(e->t, e->w, d_recs, n, pitch, d_status)));
     else
         LAUNCH(e, DJ_PROF_JOIN_LINK, (join_link_kernel<false><<<grid_for(n, LINK_BLOCK), LINK_BLOCK, 0, e->stream>>>(e->t, e->w, d_recs, n, pitch, d_status)));
-    LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, (uint32_t)n, now_ms, d_status)));
+    // h_maxchain[8] = barriers of the previous batch with 9..16 events: while there are thousands of them the
+    // register replay takes chains up to 16 (slower for everyone else, far cheaper than a wave per barrier)
+    const bool wide = e->cx_force >= 0 ? (e->cx_force & 2) != 0 : hint[8] >= WIDE_ON;
+    if (wide)
+        LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_kernel<CHAIN_REG_WIDE><<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, (uint32_t)n, now_ms, d_status)));
+    else
+        LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_kernel<CHAIN_REG><<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, (uint32_t)n, now_ms, d_status)));
     // Long chains (hot barriers): the previous batch's longest chain, read back without waiting, picks
     // between the serial kernel and the parallel cx_* kernels.  Both give the same results.
     if (e->w.cx_on) {
@@ -863,7 +871,7 @@ extern "C" int dj_checkpoint_load(dj_engine* e, const char* path) {
     HIP_TRY(e, hipMemset(e->d_sweep, 0, 2 * S_COUNT * 8));
     e->used_upper = h.used_upper;
     e->claimed_since_compact = 0;
-    e->h_maxchain[0] = e->h_maxchain[1] = 0;
+    e->h_maxchain[0] = e->h_maxchain[1] = e->h_maxchain[8] = 0;
     return DJ_OK;
 }
 

@@ -248,13 +248,17 @@ __device__ inline int32_t replay_one(const Table& t, uint64_t s, uint32_t slab, 
     return DJ_JOIN_WAITING;
 }
 
-constexpr int CHAIN_REG = 8;   // chains up to this length are replayed from registers
+// Chains up to CR events are replayed from registers.  CR = 8 is the common form; the host picks CR = 16
+// (more registers, fewer resident waves) while many barriers receive 9..16 events per batch, which would
+// otherwise each take a wave of the long-chain kernels.
+constexpr int CHAIN_REG = 8, CHAIN_REG_WIDE = 16;
 
+template <int CR>
 __global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint32_t n, uint64_t now, int32_t* status) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     // block pops of the copy pass stop at the tails as they are now (nothing touches these rings here)
     if (blockIdx.x == 0 && threadIdx.x < OVF_CLASSES) t.oring_tail_snap[threadIdx.x] = t.oring_tail[threadIdx.x];
-    bool is_complex = false;
+    bool is_complex = false, mid = false;
     uint32_t s = tid < n ? w.ev_slot[tid] : 0xFFFFFFFFu;
     // The event that linked FIRST (it found the chain empty) resolves the barrier: it knows that from
     // its own link word, so every other event leaves without touching the table again.
@@ -270,11 +274,11 @@ __global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint
         const uint32_t count = info.x, slab = info.z;
         uint32_t cur = info.w;
         // walk the chain (newest link first)
-        uint32_t idx[CHAIN_REG];
-        uint64_t nd[CHAIN_REG];
+        uint32_t idx[CR];
+        uint64_t nd[CR];
         int m = 0;
 #pragma unroll
-        for (int k = 0; k < CHAIN_REG; ++k) {
+        for (int k = 0; k < CR; ++k) {
             idx[k] = 0xFFFFFFFFu;
             nd[k] = 0;
             if (cur != 0) {
@@ -287,6 +291,7 @@ __global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint
         if (cur != 0) {
             is_complex = true;
         } else {
+            mid = m > CHAIN_REG;
             ReplayState r;
             r.count = count;
             r.bits = count > 64 ? 0 : bits0;
@@ -301,7 +306,7 @@ __global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint
                 uint32_t best = 0xFFFFFFFFu, bk = 0;
                 uint64_t bn = 0;
 #pragma unroll
-                for (int k = 0; k < CHAIN_REG; ++k)
+                for (int k = 0; k < CR; ++k)
                     if (!(done & (1u << k)) && idx[k] < best) { best = idx[k]; bk = (uint32_t)k; bn = nd[k]; }
                 done |= 1u << bk;
                 const uint32_t pos = node_pos(bn);
@@ -309,7 +314,7 @@ __global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint
                 if (st != DJ_JOIN_WAITING) status[best] = st;
                 bool last = true;   // last writer of its position inside the batch: no later event has it
 #pragma unroll
-                for (int k = 0; k < CHAIN_REG; ++k)
+                for (int k = 0; k < CR; ++k)
                     if (!(done & (1u << k)) && idx[k] != 0xFFFFFFFFu && node_pos(nd[k]) == pos) last = false;
                 if (!last) w.dst[best] = NODST;
             }
@@ -322,9 +327,13 @@ __global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint
     }
     uint32_t at = wave_append(&w.counters[C_COMPLEX], is_complex);
     if (is_complex) w.complex_[at] = s;
+    if (CR > CHAIN_REG && ((tid >> 6) & 7) == 0) {      // one wave in eight reports how many such chains it replayed
+        const uint32_t k = (uint32_t)__popcll(__ballot(mid));
+        if ((threadIdx.x & 63) == 0 && k) atomicAdd(&w.counters[C_MID], 8 * k);
+    }
 }
 
-// Barriers with more than CHAIN_REG events in the batch: one wave each.  The result of the
+// Barriers with more events in the batch than the register replay takes: one wave each.  The result of the
 // sequential replay is computed without sorting, from the first and last event index per
 // position: the barrier completes at T = max over newly present positions of the first
 // index touching it; events at or after T answer COMPLETE, the message of a position comes
@@ -341,6 +350,7 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
     __shared__ uint32_t s_len;
     const uint32_t lane = threadIdx.x;
     const uint32_t nc = w.counters[C_COMPLEX];
+    uint32_t n_mid = 0;        // chains the wide register replay would have taken (lane 0 counts)
     for (uint32_t c = blockIdx.x; c < nc; c += gridDim.x) {
         if (w.cx_on && c < CX_CAP && w.cx_off[c] != IDX_NONE) continue;       // the parallel kernels have it
         const uint32_t s = w.complex_[c];
@@ -365,6 +375,7 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
             // the atomic (they queue up on the one word) is only issued by a chain longer than the longest so far
             if (len > a_load(&w.counters[C_MAXCHAIN])) a_max(&w.counters[C_MAXCHAIN], len);
             if (len >= 256) sl->meta |= META_HOT; else sl->meta &= ~META_HOT;
+            if (len <= CHAIN_REG_WIDE) ++n_mid;
         }
         __syncthreads();
         // newly present positions: 64 positions (one bitmap word) per step, one lane per position
@@ -435,6 +446,7 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
         }
         __syncthreads();
     }
+    if (lane == 0 && n_mid) atomicAdd(&w.counters[C_MID], n_mid);            // one atomic per block
 }
 
 // ---- parallel form for hot barriers ----------------------------------------------------------
@@ -586,7 +598,7 @@ __global__ void __launch_bounds__(256) cx_scan_kernel(Work w, uint32_t n, uint64
 __global__ void __launch_bounds__(64) cx_finalize_kernel(Table t, Work w, uint64_t now) {
     const uint32_t lane = threadIdx.x;
     const uint32_t nc = min(w.counters[C_COMPLEX], CX_CAP);
-    uint32_t longest = 0;
+    uint32_t longest = 0, n_mid = 0;
     for (uint32_t c = blockIdx.x; c < nc; c += gridDim.x) {
         const uint32_t off = w.cx_off[c];
         if (off == IDX_NONE) continue;
@@ -647,10 +659,12 @@ __global__ void __launch_bounds__(64) cx_finalize_kernel(Table t, Work w, uint64
             else if (pa_pre != NQ && at_min < pa_pre) t.q[s] = at_min;
             const uint32_t events = w.cx_cnt[c];
             if (events > longest) longest = events;
+            if (events <= CHAIN_REG_WIDE) ++n_mid;
             if (events >= 256) sl->meta |= META_HOT; else sl->meta &= ~META_HOT;
         }
     }
     if (lane == 0 && longest) a_max(&w.counters[C_MAXCHAIN], longest);       // one atomic per block
+    if (lane == 0 && n_mid) atomicAdd(&w.counters[C_MID], n_mid);
 }
 
 // pass 3: messages of surviving events into the barrier's slab.  G lanes cooperate on one
@@ -669,6 +683,7 @@ __global__ void __launch_bounds__(256) join_copy_kernel(Table t, Work w, const d
     if (blockIdx.x == 0 && threadIdx.x == 0) {      // final since the resolve passes; straight into the host's memory
         w.hint[0] = w.counters[C_COMPLEX];
         w.hint[1] = w.counters[C_MAXCHAIN];
+        w.hint[8] = w.counters[C_MID];
     }
     const bool hot = w.cx_on && w.counters[C_COMPLEX] != 0;
     for (uint64_t base = wave * EPW; base < n; base += waves * EPW) {
@@ -720,6 +735,7 @@ __global__ void __launch_bounds__(256) join_copy_long_kernel(Table t, Work w, co
     if (blockIdx.x == 0 && threadIdx.x == 0) {      // final since the resolve passes; straight into the host's memory
         w.hint[0] = w.counters[C_COMPLEX];
         w.hint[1] = w.counters[C_MAXCHAIN];
+        w.hint[8] = w.counters[C_MID];
     }
     const bool hot = w.cx_on && w.counters[C_COMPLEX] != 0;
     for (uint64_t base = wave * EPW; base < n; base += waves * EPW) {      // uniform across the wave

@@ -271,7 +271,8 @@ class Engine:
         return a.value, b.value
 
     def set_hot_path(self, mode):
-        """-1 automatic, 0 serial, 1 parallel kernels for barriers with long chains (same results)."""
+        """-1 automatic, 0 serial, 1 parallel kernels for barriers with long chains; +2 pins the 16-event
+        register replay of short chains, 0 / 1 the 8-event one (same results in every mode)."""
         self._check(self.L.dj_set_hot_path(self.h, int(mode)))
 
     def checkpoint_save(self, path):

@@ -277,7 +277,10 @@ int dj_checkpoint_load(dj_engine* e, const char* path);
 /* Barriers that receive very many events in one batch (hot keys, replays) are resolved by a
  * parallel set of kernels instead of a serial walk; the engine switches by itself from the longest
  * chain of the previous batch.  Both forms give identical results; this call pins the choice
- * (-1 automatic, 0 serial, 1 parallel) so tests can exercise each.  No reference counterpart. */
+ * (-1 automatic, 0 serial, 1 parallel) so tests can exercise each.  Likewise the per-thread replay of
+ * short chains has a form for up to 8 events and one for up to 16, picked from the previous batch:
+ * adding 2 to the mode (2 serial, 3 parallel) pins the second, 0 and 1 pin the first.  No reference
+ * counterpart. */
 int dj_set_hot_path(dj_engine* e, int mode);
 
 /* ---- per-kernel timing (measurement aid; no counterpart in the reference) ---------- */

@@ -89,7 +89,7 @@ def run_oplog(d, rng, n_barriers, counts, stride, rounds, batch, hot=None, var_l
     d.check_all_snapshots()
 
 
-@pytest.mark.parametrize("hot_mode", [-1, 1])
+@pytest.mark.parametrize("hot_mode", [-1, 1, 2, 3])
 def test_small_counts_many_duplicates(oracle_lib, hot_mode):
     rng = np.random.default_rng(1)
     nb = 40
@@ -98,6 +98,22 @@ def test_small_counts_many_duplicates(oracle_lib, hot_mode):
     e, o, d = make_pair(oracle_lib, ids, 64, hot_mode=hot_mode)
     try:
         run_oplog(d, rng, nb, counts, 64, rounds=25, batch=400, unknown=5)
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("hot_mode", [-1, 0, 2])
+def test_thousands_of_barriers_with_ten_events_a_batch(oracle_lib, hot_mode):
+    """About ten events per barrier and batch on thousands of barriers: chains of 9..16 events, which the
+    engine (left to itself) moves from the long-chain kernels to the 16-event register replay after the first
+    batch; the pinned modes run the same stream through each form alone."""
+    rng = np.random.default_rng(21)
+    nb = 6000
+    ids = [f"mid{b:x}~t{b:x}" for b in range(nb)]
+    counts = rng.integers(2, 17, nb)
+    e, o, d = make_pair(oracle_lib, ids, 64, hot_mode=hot_mode, max_batch=1 << 17)
+    try:
+        run_oplog(d, rng, nb, counts, 64, rounds=5, batch=60000)
     finally:
         e.close()
 

@@ -26,6 +26,8 @@ def main():
         ("hot barrier, parallel kernels", 2000 * scale, (2, 65), 64, 15, 40000 * scale, dict(hot=7), dict(hot_mode=1)),
         ("many hot barriers", 100, (2, 65), 64, 8, 60000 * scale, dict(), dict()),
         ("many hot barriers, parallel kernels", 100, (2, 65), 64, 8, 60000 * scale, dict(), dict(hot_mode=1)),
+        ("ten events per barrier and batch", 6000, (2, 17), 64, 6, 60000 * scale, dict(), dict()),
+        ("ten events per barrier and batch, wide replay pinned", 3000, (2, 17), 64, 6, 30000 * scale, dict(), dict(hot_mode=3)),
         ("large counts", 300 * scale, (60, 1000), 64, 10, 60000 * scale, dict(hot=11), dict()),
         ("large counts, parallel kernels", 300 * scale, (60, 1000), 64, 10, 60000 * scale, dict(hot=11), dict(hot_mode=1)),
         ("variable lengths", 3000 * scale, (1, 20), 256, 12, 20000 * scale, dict(var_len=True), dict()),
