@@ -66,7 +66,7 @@ struct dj_engine {
         }                                                                      \
     } while (0)
 
-static std::string g_create_err;
+static thread_local std::string g_create_err;   // dj_create's failure text, read through dj_last_error(NULL) by the same thread
 
 static int fail(dj_engine* e, int code, const char* fmt, ...) {
     char buf[512];
@@ -280,7 +280,8 @@ extern "C" int dj_create(const dj_config* cfg, dj_engine** out) {
         return fail(nullptr, DJ_E_INVALID, "payload_stride must be a multiple of 64 in [64, 1 MiB]");
     if (cfg->max_message_bytes > (1u << 20)) return fail(nullptr, DJ_E_INVALID, "max_message_bytes must be <= 1 MiB");
     if (cfg->max_batch < 1 || cfg->max_batch > (1u << 24)) return fail(nullptr, DJ_E_INVALID, "max_batch must be 1..2^24");
-    if (cfg->capacity_barriers < 1) return fail(nullptr, DJ_E_INVALID, "capacity_barriers must be positive");
+    if (cfg->capacity_barriers < 1 || cfg->capacity_barriers > (1ull << 29))
+        return fail(nullptr, DJ_E_INVALID, "capacity_barriers must be 1..2^29");
     if (cfg->max_retry_publish > 200 || cfg->max_retry_timeout_publish > 200)
         return fail(nullptr, DJ_E_INVALID, "retry caps must be <= 200");
     if (cfg->arena_bytes / 64 < 1 + (uint64_t)slab_units(class_of(cfg->max_count), cfg->payload_stride))

@@ -84,7 +84,7 @@ typedef struct dj_engine dj_engine;
 typedef struct dj_config {
     uint32_t struct_size;               /* = sizeof(dj_config) */
     int32_t  device;                    /* HIP device ordinal */
-    uint64_t capacity_barriers;         /* max live barriers; table slots = next pow2 >= 2x.  The table keeps
+    uint64_t capacity_barriers;         /* max live barriers, 1..2^29; table slots = next pow2 >= 2x.  The table keeps
                                            working beyond it (DJ_FORK_TABLE_FULL only when no slot is left), but
                                            lookups lengthen steeply past 1.8x: size it for the peak */
     uint64_t arena_bytes;               /* payload arena size in bytes */

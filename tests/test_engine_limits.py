@@ -134,6 +134,14 @@ def test_misaligned_or_null_pointers_are_refused():
     e.close()
 
 
+def test_configurations_outside_the_limits_are_refused():
+    for kw, what in [(dict(capacity_barriers=0), "capacity_barriers"), (dict(capacity_barriers=1 << 63), "capacity_barriers"),
+                     (dict(max_count=1000), "max_count"), (dict(payload_stride=96), "payload_stride"),
+                     (dict(max_batch=0), "max_batch"), (dict(arena_bytes=64), "arena_bytes")]:
+        with pytest.raises(EngineError, match=what):
+            _engine(**kw)
+
+
 def test_long_messages_when_the_arena_runs_out():
     """Messages beyond the inline row need a block each; when the arena cannot give one the event is
     answered NO_SPACE and its position holds an empty message (the barrier stays consistent and still
