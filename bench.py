@@ -314,7 +314,8 @@ def main():
     t0 = time.perf_counter()
     ev0.record(es)
     for k in range(a.steps):
-        step(k, prefetch=min(2, a.steps - 1 - k))
+        # step numbers go on from the warm-up's (whole jobs): a barrier forked once stays forked once
+        step(warm + k, prefetch=min(2, a.steps - 1 - k))
     ev1.record(es)
     barrier()
     wall = time.perf_counter() - t0
@@ -364,16 +365,17 @@ def main():
             kernels[name] = {"avg_ms": round(avg, 4), "launches": len(v), "total_ms": round(sum(v), 4),
                              "alg_bytes_per_launch": int(per * n_units), "achieved_GBps": round(gbps, 1)}
         dom = max((k for k in kernels if kernels[k]["alg_bytes_per_launch"] > 0), key=lambda k: kernels[k]["total_ms"])
-        traffic = None
+        traffic = traffic_detail = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf) and (nb, c, P, world) == (1 << 20, 8, 64, 1) and not routed and a.hot_frac == 0 and not a.max_message and not a.max_count and not a.join_max_wait and not a.zipf_frac:
             # the counters were collected on this workload
             with open(tf) as f:
-                traffic = json.load(f).get(dom)
+                traffic_detail = json.load(f).get(dom)
+            traffic = traffic_detail.get("hbm_bytes") if traffic_detail else None     # HBM bytes per launch
         roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(kernels[dom]["achieved_GBps"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "avg_launch_ms": kernels[dom]["avg_ms"],
-                    "alg_bytes_per_launch": kernels[dom]["alg_bytes_per_launch"]}
+                    "alg_bytes_per_launch": kernels[dom]["alg_bytes_per_launch"], "traffic_detail": traffic_detail}
         # measured streaming ceiling of this GPU beside the spec peak: device-to-device copy of 1 GiB
         src, dst = torch.empty(1 << 30, dtype=torch.uint8, device=dev), torch.empty(1 << 30, dtype=torch.uint8, device=dev)
         dst.copy_(src)
