@@ -509,10 +509,10 @@ extern "C" int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs
         if (sb > 4096) sb = 4096;
         cx_scan_kernel<<<sb, 256, 0, e->stream>>>(e->w, n, now_ms);
         cx_finalize_kernel<<<1024, 64, 0, e->stream>>>(e->t, e->w, now_ms);
-        join_resolve_complex_kernel<<<4096, 64, 0, e->stream>>>(e->t, e->w, now_ms, d_status);
+        join_resolve_complex_kernel<<<4096, 64, 0, e->stream>>>(e->t, e->w, (uint32_t)n, now_ms, d_status);
         if (e->profiling) { (void)hipEventRecord(e->ev_stop[DJ_PROF_JOIN_COMPLEX], e->stream); e->ev_used[DJ_PROF_JOIN_COMPLEX] = 1; }
     } else {
-        LAUNCH(e, DJ_PROF_JOIN_COMPLEX, (join_resolve_complex_kernel<<<4096, 64, 0, e->stream>>>(e->t, e->w, now_ms, d_status)));
+        LAUNCH(e, DJ_PROF_JOIN_COMPLEX, (join_resolve_complex_kernel<<<4096, 64, 0, e->stream>>>(e->t, e->w, (uint32_t)n, now_ms, d_status)));
     }
     const uint32_t lanes = e->cfg.payload_stride / 16;
     if (lanes <= 4) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<4>(e, n, d_recs, d_payloads, pitch, d_status));

@@ -333,6 +333,54 @@ __global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint
     }
 }
 
+// One wave (a block of its own) calls f(i) for every event i of the batch that was linked to slot s (ev_slot
+// names the slot of a linked event).  The batch is read 768 events at a time, the next piece already on its
+// way; the lanes put the indices that match into the queue q (768 entries in LDS) and then take them from it
+// 64 at a time, so that whatever f loads is requested by all lanes together and not match by match.
+template <class F>
+__device__ inline void for_events_of_slot(const Work& w, uint32_t n, uint32_t s, uint32_t lane, uint32_t* q, F f) {
+    constexpr int U = 3;
+    const uint64_t quads = n >> 2;
+    const uint4* v = reinterpret_cast<const uint4*>(w.ev_slot);
+    const uint4 none = make_uint4(IDX_NONE, IDX_NONE, IDX_NONE, IDX_NONE);
+    uint4 r[U], rn[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const uint64_t g = (uint64_t)u * 64 + lane;
+        r[u] = g < quads ? v[g] : none;
+    }
+    for (uint64_t g0 = 0; g0 < quads; g0 += 64 * U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint64_t g = g0 + 64 * U + (uint64_t)u * 64 + lane;
+            rn[u] = g < quads ? v[g] : none;
+        }
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) cnt += (r[u].x == s) + (r[u].y == s) + (r[u].z == s) + (r[u].w == s);
+        const uint32_t incl = wave_incl_scan(cnt);
+        const uint32_t total = __shfl(incl, 63);
+        if (total) {                                  // the same in every lane
+            uint32_t off = incl - cnt;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t i = (uint32_t)((g0 + (uint64_t)u * 64 + lane) << 2);
+                if (r[u].x == s) q[off++] = i;
+                if (r[u].y == s) q[off++] = i + 1;
+                if (r[u].z == s) q[off++] = i + 2;
+                if (r[u].w == s) q[off++] = i + 3;
+            }
+            __syncthreads();
+            for (uint32_t k = lane; k < total; k += 64) f((uint64_t)q[k]);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) r[u] = rn[u];
+    }
+    for (uint64_t i = (quads << 2) + lane; i < n; i += 64)
+        if (w.ev_slot[i] == s) f(i);
+}
+
 // Barriers with more events in the batch than the register replay takes: one wave each.  The result of the
 // sequential replay is computed without sorting, from the first and last event index per
 // position: the barrier completes at T = max over newly present positions of the first
@@ -340,13 +388,16 @@ __global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint
 // from its last index.
 // This kernel is the serial form: lane 0 walks the chain.  It handles every long chain when the
 // parallel kernels below are off, and the barriers they could not register when they are on.
-__global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work w, uint64_t now, int32_t* status) {
+__global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work w, uint32_t n, uint64_t now, int32_t* status) {
     __shared__ uint32_t fmin[1024];
     __shared__ uint32_t fmax[1024];
     // the chain as lane 0 found it (link words and event indices): the answers are then written by all lanes
     constexpr uint32_t CHAIN_LDS = 256;
-    __shared__ uint64_t cn[CHAIN_LDS];
-    __shared__ uint32_t ci[CHAIN_LDS];
+    constexpr uint32_t LONG_WALK = 1024;      // links after which the walk is given up for a scan of the batch
+    __shared__ uint64_t cbuf[CHAIN_LDS + CHAIN_LDS / 2];
+    uint64_t* cn = cbuf;                                                   // link words
+    uint32_t* ci = reinterpret_cast<uint32_t*>(cbuf + CHAIN_LDS);           // event indices
+    uint32_t* scan_q = reinterpret_cast<uint32_t*>(cbuf);                   // the same 3 KB as a queue of 768 indices
     __shared__ uint32_t s_len;
     const uint32_t lane = threadIdx.x;
     const uint32_t nc = w.counters[C_COMPLEX];
@@ -361,8 +412,8 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
         __syncthreads();
         uint64_t at_min = NQ;      // smallest now + 1000*max-wait over the batch's waiting events
         if (lane == 0) {
-            uint32_t len = 0;
-            for (uint32_t cur = head; cur != 0; ++len) {
+            uint32_t len = 0, cur = head;
+            for (; cur != 0 && len < LONG_WALK; ++len) {
                 const uint64_t x = w.node[cur - 1];
                 const uint32_t i = cur - 1, pos = node_pos(x);
                 if (i < fmin[pos]) fmin[pos] = i;
@@ -370,7 +421,7 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
                 if (len < CHAIN_LDS) { cn[len] = x; ci[len] = i; }
                 cur = node_next(x);
             }
-            s_len = len;
+            s_len = cur != 0 ? IDX_NONE : len;       // IDX_NONE: gave up, the wave scans the batch instead
             // the host picks the parallel kernels for the next batch from this; thousands of barriers report, so
             // the atomic (they queue up on the one word) is only issued by a chain longer than the longest so far
             if (len > a_load(&w.counters[C_MAXCHAIN])) a_max(&w.counters[C_MAXCHAIN], len);
@@ -378,6 +429,25 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
             if (len <= CHAIN_REG_WIDE) ++n_mid;
         }
         __syncthreads();
+        const bool scan = s_len == IDX_NONE;
+        if (scan) {
+            // A chain of thousands of links on a barrier nobody knew to be hot (the first batch of a replay storm):
+            // one lane would walk it at about 0.6 us per link.  The events of a barrier are exactly those whose
+            // ev_slot names its slot, so the wave reads that array once instead, four events per lane and step.
+            uint32_t mine = 0;
+            for_events_of_slot(w, n, s, lane, scan_q, [&](uint64_t i) {
+                const uint32_t pos = node_pos(w.node[i]);
+                atomicMin(&fmin[pos], (uint32_t)i);
+                atomicMax(&fmax[pos], (uint32_t)i + 1);
+                ++mine;
+            });
+            for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
+            if (lane == 0) {
+                if (mine > a_load(&w.counters[C_MAXCHAIN])) a_max(&w.counters[C_MAXCHAIN], mine);
+                sl->meta |= META_HOT;
+            }
+            __syncthreads();
+        }
         // newly present positions: 64 positions (one bitmap word) per step, one lane per position
         uint32_t t_complete = 0, n_new = 0;
         const uint32_t words = (count + 63) >> 6;
@@ -420,14 +490,15 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
             if (fmax[pos] != i + 1) w.dst[i] = NODST;
             return at;
         };
-        if (len <= CHAIN_LDS) {                   // all lanes, from the copy in LDS
+        if (scan) {                               // all lanes, over the batch once more
+            for_events_of_slot(w, n, s, lane, scan_q, [&](uint64_t i) {
+                const uint64_t at = answer(w.node[i], (uint32_t)i);
+                if (at < at_min) at_min = at;
+            });
+        } else if (len <= CHAIN_LDS) {            // all lanes, from the copy in LDS
             for (uint32_t k = lane; k < len; k += 64) {
                 const uint64_t at = answer(cn[k], ci[k]);
                 if (at < at_min) at_min = at;
-            }
-            for (int off = 32; off > 0; off >>= 1) {
-                const uint64_t o = ((uint64_t)__shfl_xor((uint32_t)(at_min >> 32), off) << 32) | __shfl_xor((uint32_t)at_min, off);
-                if (o < at_min) at_min = o;
             }
         } else if (lane == 0) {                   // longer than the copy: walk again
             for (uint32_t cur = head; cur != 0;) {
@@ -436,6 +507,10 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
                 if (at < at_min) at_min = at;
                 cur = node_next(x);
             }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const uint64_t o = ((uint64_t)__shfl_xor((uint32_t)(at_min >> 32), off) << 32) | __shfl_xor((uint32_t)at_min, off);
+            if (o < at_min) at_min = o;
         }
         if (lane == 0) {
             sl->bits = count > 64 ? (uint64_t)arrived : bits0;

@@ -132,6 +132,23 @@ def test_hot_barrier_long_chains(oracle_lib, hot_mode):
         e.close()
 
 
+@pytest.mark.parametrize("hot_mode", [-1, 0])
+def test_chain_longer_than_one_lane_walks(oracle_lib, hot_mode):
+    """A third of a 30 000-event batch on one barrier that nobody knew to be hot: the serial long-chain
+    kernel gives the walk up after 1024 links and scans the batch instead (every batch with the serial
+    kernels pinned, the first batch when the engine picks)."""
+    rng = np.random.default_rng(31)
+    nb = 40
+    ids = [f"storm{b}~t{b}" for b in range(nb)]
+    counts = rng.integers(2, 64, nb)
+    counts[5] = 33
+    e, o, d = make_pair(oracle_lib, ids, 64, hot_mode=hot_mode, max_batch=1 << 15)
+    try:
+        run_oplog(d, rng, nb, counts, 64, rounds=5, batch=30001, hot=5)
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("hot_mode", [-1, 1])
 def test_many_hot_barriers_at_once(oracle_lib, hot_mode):
     """Every barrier receives hundreds of events per batch, so all of them get flagged hot: more hot barriers
