@@ -140,6 +140,8 @@ join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t 
     bool stores_meta = false;      // this event writes its position's {len, max-wait} word
     int agg_key = -1;
     uint32_t agg_rank = 0, agg_pos = 0, agg_mw = 0;
+    bool need_x = false;           // this event still has to put itself at the head of its barrier's chain
+    uint32_t x_pos = 0, x_mw = 0;
     if (i < n) {
         const ulonglong2 a = reinterpret_cast<const ulonglong2*>(recs)[2 * (size_t)i];
         const uint4 b = reinterpret_cast<const uint4*>(recs)[2 * (size_t)i + 1];  // position, len, max_wait, -
@@ -184,11 +186,39 @@ join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t 
                     }
                 }
             }
-            if (agg_key < 0) {
-                const uint32_t prev = a_xchg(&t.slots[s].chain, i + 1);
-                w.node[i] = node_pack(prev, b.x, b.z);
+            if (agg_key < 0) { need_x = true; x_pos = b.x; x_mw = b.z; }
+        }
+    }
+    // Many lanes of one wave on the same barrier (a barrier turning hot before anyone has flagged it): they
+    // chain among themselves and issue ONE exchange, instead of queueing up on the chain word at 20-40 ns each.
+    // Two candidates per wave, the barriers of its first and of its last such lane; a batch without a hot
+    // barrier never gets past the popcount.
+    {
+        const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const uint64_t rem = __ballot(need_x);
+            if (rem == 0) break;
+            const int l0 = r == 0 ? __ffsll((unsigned long long)rem) - 1 : 63 - __clzll((unsigned long long)rem);
+            const uint32_t s0 = __shfl(slot, l0);
+            const uint64_t grp = __ballot(need_x && slot == s0);
+            if (__popcll(grp) < 4) continue;
+            const int hi = 63 - __clzll((unsigned long long)grp);
+            uint32_t prev = 0;
+            if ((int)lane == hi) prev = a_xchg(&t.slots[slot].chain, i + 1);
+            prev = __shfl(prev, hi);
+            if (need_x && slot == s0) {
+                const uint64_t below = grp & ((1ull << lane) - 1);
+                // the next lower lane of the group (its event index is i minus the lane distance), or the chain as it was
+                const uint32_t next = below ? i - (lane - (uint32_t)(63 - __clzll((unsigned long long)below))) + 1 : prev;
+                w.node[i] = node_pack(next, x_pos, x_mw);
+                need_x = false;
             }
         }
+    }
+    if (need_x) {
+        const uint32_t prev = a_xchg(&t.slots[slot].chain, i + 1);
+        w.node[i] = node_pack(prev, x_pos, x_mw);
     }
     // a sample for the host: how ragged is the traffic (it decides how the next barriers are forked)
     if (blockIdx.x == 0 && threadIdx.x < 256) {
