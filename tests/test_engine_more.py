@@ -859,3 +859,72 @@ def test_config4_one_rank_full_size_properties():
         assert e.stats()["live"] == 0
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("hot_mode", [-1, 0])
+def test_replay_storm_at_full_batch_size(hot_mode):
+    """Half of a 1 M-event batch on ONE barrier (count 64, positions 0..62, so it cannot complete) that the
+    engine has never seen hot, the other half spread over 128 K barriers of count 8; then the same again with
+    other bytes (by now the barrier is flagged, and left to itself the engine has the parallel kernels on;
+    pinned to the serial kernels, both batches take the chain walk that gives up and scans the batch), then the
+    missing position.  Checked from the generator's arithmetic: every storm event is answered WAITING, the
+    barrier's positions hold the bytes of the LAST event in array order, exactly those of the 128 K barriers
+    complete whose eight positions were all in the batch, and the last join completes the storm barrier."""
+    import torch
+    nb, c, c_hot, P, n = 1 << 17, 8, 64, 64, 1 << 20
+    ids = [f"q{b:x}~t{b:x}" for b in range(nb + 1)]
+    fps_np = capi.fingerprint_many(ids).view(np.int64)
+    e = _engine(capacity_barriers=nb + 1, arena_bytes=nb * (c * P + 128) + (64 << 20), max_count=c_hot,
+                payload_stride=P, max_batch=n)
+    e.set_hot_path(hot_mode)
+    dev = e.device
+    try:
+        g = torch.Generator(device=dev)
+        g.manual_seed(77)
+        fps = torch.from_numpy(fps_np).to(dev)
+        frecs = torch.empty((nb + 1, 4), dtype=torch.int64, device=dev)
+        frecs[:, 0], frecs[:, 1], frecs[:, 2], frecs[:, 3] = fps[:, 0], fps[:, 1], c, T0 + 3_600_000
+        frecs[nb, 2] = c_hot
+        d_status = torch.empty(n, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        e.fork_batch_dev(nb + 1, frecs, d_status)
+        e.sync()
+        assert bool((d_status[:nb + 1] == capi.DJ_FORK_CREATED).all())
+        half = n // 2
+        for rnd in range(2):
+            # the ordinary half: half of the 1 M (barrier, position) cells, each at most once per batch
+            cells = torch.randperm(nb * c, device=dev, generator=g)[:half]
+            b_of = torch.cat([cells // c, torch.full((half,), nb, dtype=torch.int64, device=dev)])
+            p_of = torch.cat([cells % c, torch.randint(0, c_hot - 1, (half,), device=dev, generator=g)])
+            perm = torch.randperm(n, device=dev, generator=g)
+            b_of, p_of = b_of[perm], p_of[perm]
+            recs = torch.empty((n, 4), dtype=torch.int64, device=dev)
+            recs[:, 0], recs[:, 1], recs[:, 2], recs[:, 3] = fps[b_of, 0], fps[b_of, 1], p_of | (P << 32), 0
+            pay = torch.randint(0, 256, (n, P), dtype=torch.uint8, device=dev, generator=g)
+            torch.cuda.synchronize()        # the engine has a stream of its own: the inputs must be complete
+            e.join_batch_dev(n, recs, pay, P, T0 + 1 + rnd, d_status)
+            e.sync()
+            storm = b_of == nb
+            vals, cnts = torch.unique(d_status[storm], return_counts=True)
+            assert vals.tolist() == [capi.DJ_JOIN_WAITING], (rnd, vals.tolist(), cnts.tolist())
+            if rnd == 0:
+                per_barrier = torch.bincount(b_of[~storm], minlength=nb)
+                assert int((d_status[~storm] == capi.DJ_JOIN_COMPLETE).sum()) == int((per_barrier == c).sum())
+                assert bool(((d_status[~storm] == capi.DJ_JOIN_WAITING) | (d_status[~storm] == capi.DJ_JOIN_COMPLETE)).all())
+            idx = torch.arange(n, device=dev)
+            last = torch.full((c_hot,), -1, dtype=torch.int64, device=dev).scatter_reduce(0, p_of[storm], idx[storm], "amax")
+            meta, lens, mws, got = e.snapshot_one(int(fps_np[nb, 0]) & (2**64 - 1), int(fps_np[nb, 1]) & (2**64 - 1))
+            assert int(meta["count"]) == c_hot
+            assert bool((last[:c_hot - 1] >= 0).all())
+            assert list(lens[:c_hot - 1]) == [P] * (c_hot - 1) and lens[c_hot - 1] == capi.DJ_NIL
+            want = pay[last[:c_hot - 1]].cpu().numpy()
+            assert np.array_equal(np.asarray(got[:c_hot - 1]), want)
+        # the missing position completes it
+        one = torch.empty((1, 4), dtype=torch.int64, device=dev)
+        one[0, 0], one[0, 1], one[0, 2], one[0, 3] = fps[nb, 0], fps[nb, 1], (c_hot - 1) | (P << 32), 0
+        torch.cuda.synchronize()
+        e.join_batch_dev(1, one, pay[:1], P, T0 + 5, d_status)
+        e.sync()
+        assert int(d_status[0]) == capi.DJ_JOIN_COMPLETE
+    finally:
+        e.close()
