@@ -19,6 +19,10 @@
  *    otherwise; dj_sync() waits for them.  Calls on one engine serialise themselves
  *    (one engine = one stream = one internal mutex), so threads may share an engine;
  *    the ORDER of their batches is then theirs to arrange (include/dj_batcher.h does).
+ *    The stream is the engine's own (non-blocking: it does not wait for the null stream):
+ *    a d_* input written by work on another stream must be complete before the call
+ *    (wait for that stream, or make dj_stream() wait for an event recorded on it), and
+ *    outputs are to be read after dj_sync() or from work ordered behind dj_stream().
  *  - the engine never reads a clock: now_ms is always an argument.  It must be a
  *    13-digit epoch-milliseconds value (1e12 <= now_ms < 9e12): inside that range
  *    the reference's Lua string comparison of scores (redis.clj:268-269) equals the
