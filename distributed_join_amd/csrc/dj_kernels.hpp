@@ -423,7 +423,9 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
     __shared__ uint32_t fmax[1024];
     // the chain as lane 0 found it (link words and event indices): the answers are then written by all lanes
     constexpr uint32_t CHAIN_LDS = 256;
-    constexpr uint32_t LONG_WALK = 1024;      // links after which the walk is given up for a scan of the batch
+    // Links after which the walk is given up for a scan of the batch: a link costs about 0.6 us, the two scans
+    // about 2.9 ns per event of the batch, so the walk of n / 512 links costs less than half of what follows.
+    const uint32_t long_walk = max(256u, n >> 9);
     __shared__ uint64_t cbuf[CHAIN_LDS + CHAIN_LDS / 2];
     uint64_t* cn = cbuf;                                                   // link words
     uint32_t* ci = reinterpret_cast<uint32_t*>(cbuf + CHAIN_LDS);           // event indices
@@ -443,7 +445,7 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
         uint64_t at_min = NQ;      // smallest now + 1000*max-wait over the batch's waiting events
         if (lane == 0) {
             uint32_t len = 0, cur = head;
-            for (; cur != 0 && len < LONG_WALK; ++len) {
+            for (; cur != 0 && len < long_walk; ++len) {
                 const uint64_t x = w.node[cur - 1];
                 const uint32_t i = cur - 1, pos = node_pos(x);
                 if (i < fmin[pos]) fmin[pos] = i;

@@ -135,7 +135,7 @@ def test_hot_barrier_long_chains(oracle_lib, hot_mode):
 @pytest.mark.parametrize("hot_mode", [-1, 0])
 def test_chain_longer_than_one_lane_walks(oracle_lib, hot_mode):
     """A third of a 30 000-event batch on one barrier that nobody knew to be hot: the serial long-chain
-    kernel gives the walk up after 1024 links and scans the batch instead (every batch with the serial
+    kernel gives the walk up after 256 links (batch size / 512, at least 256) and scans the batch instead (every batch with the serial
     kernels pinned, the first batch when the engine picks)."""
     rng = np.random.default_rng(31)
     nb = 40
