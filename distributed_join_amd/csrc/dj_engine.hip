@@ -199,9 +199,11 @@ static int create_impl(dj_engine* e) {
     ALLOC(e, t.stat, 4 * 8);
     const uint32_t max_class = class_of(c.max_count);
     for (uint32_t k = 0; k < NUM_CLASSES; ++k) {
-        // live + freed slabs of a class can never exceed arena / slab size
+        // slabs of a class that can exist at once: bounded by arena / slab size, and (one slab per barrier, the
+        // ring holding only slabs that no slot refers to) by the number of table slots, which is what bounds
+        // the live barriers (more than capacity_barriers of them are accepted while slots are left)
         uint64_t cap = k <= max_class ? t.arena_units / slab_units(k, t.stride) + 1 : 1;
-        if (cap > c.capacity_barriers * 2 + 1) cap = c.capacity_barriers * 2 + 1;
+        if (cap > slots + 1) cap = slots + 1;
         cap = next_pow2(cap);
         t.ring_cap[k] = (uint32_t)cap;
         ALLOC(e, t.ring[k], cap * 4);

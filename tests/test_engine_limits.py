@@ -120,6 +120,36 @@ def test_full_table_and_exhausted_arena_are_reported_per_record():
     e.close()
 
 
+def test_mass_delete_beyond_capacity_barriers_keeps_slabs_apart():
+    """More live barriers than capacity_barriers (the table takes them while slots are left) are all deleted
+    at once: every slab must come back through the free lists exactly once, so that the next generation of
+    barriers gets a slab each and keeps its own bytes."""
+    e = _engine(capacity_barriers=64, arena_bytes=8 << 20, max_count=1, payload_stride=64, max_batch=2048,
+                host_cap_conts=2048, host_cap_positions=4096)
+    ids = [f"gen~{k}" for k in range(1024)]
+    used = None
+    for gen in range(3):
+        assert (e.fork_batch(_forks(ids, 1)) == capi.DJ_FORK_CREATED).all()
+        pay = np.zeros((1024, 64), np.uint8)
+        pay[:, :8] = (np.arange(1024, dtype=np.uint64) * 2654435761 + gen).view(np.uint8).reshape(1024, 8)
+        assert (e.join_batch(_joins(ids, 0, length=8), pay, T0 + gen) == capi.DJ_JOIN_COMPLETE).all()
+        conts, lens, _, out, more = e.sweep(T0 + gen)
+        assert len(conts) == 1024 and not more
+        fps = capi.fingerprint_many(ids)
+        index = {(int(a), int(b)): k for k, (a, b) in enumerate(fps)}
+        for c in conts:
+            k = index[(int(c["fp_lo"]), int(c["fp_hi"]))]
+            assert bytes(out[int(c["pos_base"]), :8]) == bytes(pay[k, :8]), f"generation {gen}: barrier {k} holds another's bytes"
+        assert (e.ack_batch(conts, None, T0 + gen) == capi.DJ_ACK_DONE).all()
+        st = e.stats()
+        assert st["live"] == 0
+        # nothing leaks: what the bump pointer handed out sits in the free lists, and does not grow per generation
+        assert st["arena_units_free"] == st["arena_units_used"] - 1
+        used = used or st["arena_units_used"]
+        assert st["arena_units_used"] == used
+    e.close()
+
+
 def test_misaligned_or_null_pointers_are_refused():
     import torch
     e = _engine()
