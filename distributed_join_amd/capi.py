@@ -24,6 +24,7 @@ DJ_ACK_DONE, DJ_ACK_REQUEUED_DIRTY, DJ_ACK_RETRY = 1, 2, 3
 DJ_ACK_DROPPED_EXHAUSTED, DJ_ACK_DONE_NO_METADATA = 4, 5
 DJ_CONT_TIMEOUT, DJ_CONT_NO_METADATA = 1, 2
 DJ_CONT_VOID = CONT_VOID = 0x80000000
+DJ_STATIC_JOIN_MAX = 65536
 
 # ---- record layouts (little-endian, no padding surprises: all fields naturally aligned)
 FORK_REC = np.dtype([("fp_lo", "<u8"), ("fp_hi", "<u8"), ("count", "<u4"), ("reserved", "<u4"),
@@ -56,7 +57,7 @@ SYMBOLS = ["dj_create", "dj_destroy", "dj_last_error", "dj_sync", "dj_stream", "
            "dj_ack_batch", "dj_recover", "dj_snapshot_one", "dj_store_in_publish_queue",
            "dj_queue_scores", "dj_get_stats", "dj_owner_of", "dj_partition_joins", "dj_profile_enable",
            "dj_profile_read", "dj_compact", "dj_set_hot_path", "dj_checkpoint_save", "dj_checkpoint_load",
-           "dj_get_config", "dj_fetch_long"]
+           "dj_get_config", "dj_fetch_long", "dj_join_batch_static"]
 # include/dj_batcher.h
 BATCHER_SYMBOLS = ["dj_batcher_create", "dj_batcher_destroy", "dj_batcher_set_clock", "dj_batcher_join",
                    "dj_batcher_fork", "dj_batcher_join_wait", "dj_batcher_fork_wait", "dj_batcher_run",
@@ -115,6 +116,8 @@ def load():
     L.dj_fork_batch.argtypes = [vp, u32, vp, vp]
     L.dj_join_batch.restype = i32
     L.dj_join_batch.argtypes = [vp, u32, vp, vp, u64, u64, vp]
+    L.dj_join_batch_static.restype = i32
+    L.dj_join_batch_static.argtypes = [vp, u32, vp, vp, u64, u64, vp]
     L.dj_pop_due.restype = i32
     L.dj_pop_due.argtypes = [vp, u64, u32, vp, vp, vp]
     L.dj_sweep.restype = i32

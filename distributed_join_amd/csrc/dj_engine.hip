@@ -17,6 +17,26 @@
 
 using namespace dj;
 
+// ---- scratch of dj_join_batch_static -----------------------------------------------------------
+// The per-batch work arrays of a join batch (link words, message destinations, event-to-slot map, list of
+// long chains, counters) for batches of at most DJ_STATIC_JOIN_MAX events, as a device array of the code
+// object instead of hipMalloc memory.  Every GPU the library runs on holds its own copy at its own
+// address; `scratch` itself is only the host-side handle of the symbol: host code uses the per-device
+// address from hipGetSymbolAddress (g_scratch), resolved by dj_create with that device current.
+namespace {
+constexpr size_t SCR_NODE = 0;
+constexpr size_t SCR_DST = SCR_NODE + (size_t)DJ_STATIC_JOIN_MAX * 8;
+constexpr size_t SCR_EV_SLOT = SCR_DST + (size_t)DJ_STATIC_JOIN_MAX * 8;
+constexpr size_t SCR_COMPLEX = SCR_EV_SLOT + (size_t)DJ_STATIC_JOIN_MAX * 4;
+constexpr size_t SCR_COUNTERS = SCR_COMPLEX + (size_t)DJ_STATIC_JOIN_MAX * 4;
+constexpr size_t SCR_BYTES = SCR_COUNTERS + 256;       // two banks of C_COUNT counters
+static_assert(2 * C_COUNT * 4 <= 256, "counter banks must fit their 256 bytes");
+constexpr int SCR_MAX_DEVICES = 64;
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[SCR_BYTES];
+static unsigned char* g_scratch[SCR_MAX_DEVICES];      // device address of `scratch` on each device, nullptr = not resolved
+static std::mutex g_scratch_mu;
+
 struct dj_engine {
     dj_config cfg;
     Table t;
@@ -53,6 +73,7 @@ struct dj_engine {
     int profiling;
     hipEvent_t ev_start[DJ_PROF_KERNELS], ev_stop[DJ_PROF_KERNELS];
     int ev_used[DJ_PROF_KERNELS];
+    unsigned char* scratch_ptr;  // this device's copy of the static scratch array (dj_join_batch_static)
 };
 
 // Launch `call` on the engine's stream; with profiling on, bracket it with the kernel id's events.
@@ -167,6 +188,16 @@ static int create_impl(dj_engine* e) {
     const dj_config& c = e->cfg;
     HIP_TRY(e, hipSetDevice(c.device));
     HIP_TRY(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    if (c.device < 0 || c.device >= SCR_MAX_DEVICES) return fail(e, DJ_E_INVALID, "device ordinal must be 0..%d", SCR_MAX_DEVICES - 1);
+    {   // once per device, with that device current
+        std::lock_guard<std::mutex> g(g_scratch_mu);
+        if (!g_scratch[c.device]) {
+            unsigned char* p = nullptr;
+            HIP_TRY(e, hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+            g_scratch[c.device] = p;
+        }
+        e->scratch_ptr = g_scratch[c.device];
+    }
     Table& t = e->t;
     memset(&t, 0, sizeof t);
     uint64_t slots = next_pow2(c.capacity_barriers * 2);
@@ -297,6 +328,7 @@ extern "C" int dj_create(const dj_config* cfg, dj_engine** out) {
     e->h_maxchain = nullptr;
     e->compact_ev = nullptr;
     e->cx_force = -1;
+    e->scratch_ptr = nullptr;
     for (int k = 0; k < DJ_PROF_KERNELS; ++k) { e->ev_start[k] = nullptr; e->ev_stop[k] = nullptr; e->ev_used[k] = 0; }
     int rc = create_impl(e);
     if (rc != DJ_OK) {
@@ -454,34 +486,35 @@ extern "C" int dj_fork_batch(dj_engine* e, uint32_t n, const dj_fork_rec* d_recs
 }
 
 template <int G>
-static void launch_join_copy(dj_engine* e, uint32_t n, const dj_join_rec* recs, const uint8_t* payloads, uint64_t pitch,
+static void launch_join_copy(dj_engine* e, const Work& w, uint32_t n, const dj_join_rec* recs, const uint8_t* payloads, uint64_t pitch,
                              int32_t* status) {
     const uint64_t steps = ((uint64_t)n + (64 / G) - 1) / (64 / G);          // wave steps
     uint64_t blocks = (steps + 3) / 4;
     if (blocks > 8192) blocks = 8192;
     if (e->t.max_message > e->t.stride)
-        join_copy_long_kernel<G><<<(uint32_t)blocks, 256, 0, e->stream>>>(e->t, e->w, recs, payloads, pitch, n, status);
+        join_copy_long_kernel<G><<<(uint32_t)blocks, 256, 0, e->stream>>>(e->t, w, recs, payloads, pitch, n, status);
     else
-        join_copy_kernel<G><<<(uint32_t)blocks, 256, 0, e->stream>>>(e->t, e->w, recs, payloads, pitch, n, status);
+        join_copy_kernel<G><<<(uint32_t)blocks, 256, 0, e->stream>>>(e->t, w, recs, payloads, pitch, n, status);
 }
 
 constexpr unsigned int WIDE_ON = 2048;   // barriers with 9..16 events in a batch from which the wide replay pays
 
-extern "C" int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs, const uint8_t* d_payloads,
-                             uint64_t pitch, uint64_t now_ms, int32_t* d_status) {
-    if (!e) return DJ_E_INVALID;
-    std::lock_guard<std::recursive_mutex> guard(e->mu);
-    if (!clock_ok(now_ms)) return fail(e, DJ_E_CLOCK_RANGE, "join: now_ms=%llu outside [1e12, 9e12)", (unsigned long long)now_ms);
+static int join_check(dj_engine* e, const char* what, uint32_t n, const dj_join_rec* d_recs, const uint8_t* d_payloads,
+                      uint64_t pitch, uint64_t now_ms, const int32_t* d_status, uint32_t max_n, const char* limit) {
+    if (!clock_ok(now_ms)) return fail(e, DJ_E_CLOCK_RANGE, "%s: now_ms=%llu outside [1e12, 9e12)", what, (unsigned long long)now_ms);
     if (n == 0) return DJ_OK;
-    if (!d_recs || !d_status || !d_payloads) return fail(e, DJ_E_INVALID, "join: null pointer");
+    if (!d_recs || !d_status || !d_payloads) return fail(e, DJ_E_INVALID, "%s: null pointer", what);
     if (!aligned16(d_recs) || !aligned16(d_payloads) || pitch % 16 || pitch == 0)
-        return fail(e, DJ_E_INVALID, "join: records and payloads must be 16-byte aligned, pitch a positive multiple of 16");
-    if (n > e->cfg.max_batch) return fail(e, DJ_E_TOO_LARGE, "join: n=%u exceeds max_batch=%u", n, e->cfg.max_batch);
-    HIP_TRY(e, hipSetDevice(e->cfg.device));
-    // double-banked counters: this batch counts in one bank and zeroes the other for the next batch
-    e->w.counters = e->d_counters + e->ctr_bank * C_COUNT;
-    e->w.counters_next = e->d_counters + (e->ctr_bank ^ 1) * C_COUNT;
-    e->ctr_bank ^= 1;
+        return fail(e, DJ_E_INVALID, "%s: records and payloads must be 16-byte aligned, pitch a positive multiple of 16", what);
+    if (n > max_n) return fail(e, DJ_E_TOO_LARGE, "%s: n=%u exceeds %s=%u", what, n, limit, max_n);
+    return DJ_OK;
+}
+
+// The join passes on the engine's stream with the work arrays of `w`.  serial_only: long chains take the
+// one-wave-per-barrier kernel whatever the previous batch looked like (the parallel kernels' tables are not
+// part of every work set); both forms give the same results.
+static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, const dj_join_rec* d_recs,
+                       const uint8_t* d_payloads, uint64_t pitch, uint64_t now_ms, int32_t* d_status) {
     // h_maxchain[0] = barriers with long chains in the previous batch, [1] = its longest chain
     const volatile unsigned int* hint = e->h_maxchain;
     // The serial kernel walks one chain per wave on 2048 blocks, about 0.6 us per link: its time grows with
@@ -489,41 +522,77 @@ extern "C" int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs
     // look like (measured: 100 barriers x 250 events and 500 x 200 break even, 8192 x 128 and anything longer
     // than the serial kernel's 256-entry chain copy go parallel, 2000 x 50 and 8000 x 12 stay serial).
     const unsigned int rounds = hint[0] / 2048 + 1;
-    e->w.cx_on = e->cx_force >= 0 ? (uint32_t)(e->cx_force & 1) : ((uint64_t)rounds * hint[1] > 256 ? 1u : 0u);
-    if (e->w.cx_on)
-        LAUNCH(e, DJ_PROF_JOIN_LINK, (join_link_kernel<true><<<grid_for(n, LINK_BLOCK_HOT), LINK_BLOCK_HOT, 0, e->stream>>>(e->t, e->w, d_recs, n, pitch, d_status)));
+    w.cx_on = serial_only ? 0u : e->cx_force >= 0 ? (uint32_t)(e->cx_force & 1) : ((uint64_t)rounds * hint[1] > 256 ? 1u : 0u);
+    if (w.cx_on)
+        LAUNCH(e, DJ_PROF_JOIN_LINK, (join_link_kernel<true><<<grid_for(n, LINK_BLOCK_HOT), LINK_BLOCK_HOT, 0, e->stream>>>(e->t, w, d_recs, n, pitch, d_status)));
     else
-        LAUNCH(e, DJ_PROF_JOIN_LINK, (join_link_kernel<false><<<grid_for(n, LINK_BLOCK), LINK_BLOCK, 0, e->stream>>>(e->t, e->w, d_recs, n, pitch, d_status)));
+        LAUNCH(e, DJ_PROF_JOIN_LINK, (join_link_kernel<false><<<grid_for(n, LINK_BLOCK), LINK_BLOCK, 0, e->stream>>>(e->t, w, d_recs, n, pitch, d_status)));
     // h_maxchain[8] = barriers of the previous batch with 9..16 events: while there are thousands of them the
     // register replay takes chains up to 16 (slower for everyone else, far cheaper than a wave per barrier)
     const bool wide = e->cx_force >= 0 ? (e->cx_force & 2) != 0 : hint[8] >= WIDE_ON;
     if (wide)
-        LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_kernel<CHAIN_REG_WIDE><<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, (uint32_t)n, now_ms, d_status)));
+        LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_kernel<CHAIN_REG_WIDE><<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, w, (uint32_t)n, now_ms, d_status)));
     else
-        LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_kernel<CHAIN_REG><<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, (uint32_t)n, now_ms, d_status)));
+        LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_kernel<CHAIN_REG><<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, w, (uint32_t)n, now_ms, d_status)));
     // Long chains (hot barriers): the previous batch's longest chain, read back without waiting, picks
     // between the serial kernel and the parallel cx_* kernels.  Both give the same results.
-    if (e->w.cx_on) {
-        HIP_TRY(e, hipMemsetAsync(e->w.cx_keys, 0, CX_HASH * 4, e->stream));
+    if (w.cx_on) {
+        HIP_TRY(e, hipMemsetAsync(w.cx_keys, 0, CX_HASH * 4, e->stream));
         if (e->profiling) (void)hipEventRecord(e->ev_start[DJ_PROF_JOIN_COMPLEX], e->stream);
-        cx_init_kernel<<<CX_CAP / CX_BPB, 256, 0, e->stream>>>(e->t, e->w);
+        cx_init_kernel<<<CX_CAP / CX_BPB, 256, 0, e->stream>>>(e->t, w);
         uint32_t sb = grid_for(n, 256);
         if (sb > 4096) sb = 4096;
-        cx_scan_kernel<<<sb, 256, 0, e->stream>>>(e->w, n, now_ms);
-        cx_finalize_kernel<<<1024, 64, 0, e->stream>>>(e->t, e->w, now_ms);
-        join_resolve_complex_kernel<<<4096, 64, 0, e->stream>>>(e->t, e->w, (uint32_t)n, now_ms, d_status);
+        cx_scan_kernel<<<sb, 256, 0, e->stream>>>(w, n, now_ms);
+        cx_finalize_kernel<<<1024, 64, 0, e->stream>>>(e->t, w, now_ms);
+        join_resolve_complex_kernel<<<4096, 64, 0, e->stream>>>(e->t, w, (uint32_t)n, now_ms, d_status);
         if (e->profiling) { (void)hipEventRecord(e->ev_stop[DJ_PROF_JOIN_COMPLEX], e->stream); e->ev_used[DJ_PROF_JOIN_COMPLEX] = 1; }
     } else {
-        LAUNCH(e, DJ_PROF_JOIN_COMPLEX, (join_resolve_complex_kernel<<<4096, 64, 0, e->stream>>>(e->t, e->w, (uint32_t)n, now_ms, d_status)));
+        LAUNCH(e, DJ_PROF_JOIN_COMPLEX, (join_resolve_complex_kernel<<<4096, 64, 0, e->stream>>>(e->t, w, (uint32_t)n, now_ms, d_status)));
     }
     const uint32_t lanes = e->cfg.payload_stride / 16;
-    if (lanes <= 4) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<4>(e, n, d_recs, d_payloads, pitch, d_status));
-    else if (lanes <= 8) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<8>(e, n, d_recs, d_payloads, pitch, d_status));
-    else if (lanes <= 16) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<16>(e, n, d_recs, d_payloads, pitch, d_status));
-    else if (lanes <= 32) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<32>(e, n, d_recs, d_payloads, pitch, d_status));
-    else LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<64>(e, n, d_recs, d_payloads, pitch, d_status));
+    if (lanes <= 4) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<4>(e, w, n, d_recs, d_payloads, pitch, d_status));
+    else if (lanes <= 8) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<8>(e, w, n, d_recs, d_payloads, pitch, d_status));
+    else if (lanes <= 16) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<16>(e, w, n, d_recs, d_payloads, pitch, d_status));
+    else if (lanes <= 32) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<32>(e, w, n, d_recs, d_payloads, pitch, d_status));
+    else LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<64>(e, w, n, d_recs, d_payloads, pitch, d_status));
     HIP_TRY(e, hipGetLastError());
     return DJ_OK;
+}
+
+extern "C" int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs, const uint8_t* d_payloads,
+                             uint64_t pitch, uint64_t now_ms, int32_t* d_status) {
+    if (!e) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
+    const int rc = join_check(e, "join", n, d_recs, d_payloads, pitch, now_ms, d_status, e->cfg.max_batch, "max_batch");
+    if (rc != DJ_OK || n == 0) return rc;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    // double-banked counters: this batch counts in one bank and zeroes the other for the next batch
+    e->w.counters = e->d_counters + e->ctr_bank * C_COUNT;
+    e->w.counters_next = e->d_counters + (e->ctr_bank ^ 1) * C_COUNT;
+    e->ctr_bank ^= 1;
+    return join_launch(e, e->w, false, n, d_recs, d_payloads, pitch, now_ms, d_status);
+}
+
+extern "C" int dj_join_batch_static(dj_engine* e, uint32_t n, const dj_join_rec* d_recs, const uint8_t* d_payloads,
+                                    uint64_t pitch, uint64_t now_ms, int32_t* d_status) {
+    if (!e) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
+    const int rc = join_check(e, "join_static", n, d_recs, d_payloads, pitch, now_ms, d_status, DJ_STATIC_JOIN_MAX, "DJ_STATIC_JOIN_MAX");
+    if (rc != DJ_OK || n == 0) return rc;
+    if (!e->scratch_ptr) return fail(e, DJ_E_INVALID, "join_static: the scratch array was not resolved on device %d", e->cfg.device);
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    // the array keeps the previous call's contents: the counters must start at zero (the other arrays are
+    // written before they are read, element by element, by the link pass)
+    unsigned char* p = e->scratch_ptr;
+    HIP_TRY(e, hipMemsetAsync(p + SCR_COUNTERS, 0, 256, e->stream));
+    Work w = e->w;            // hint, sweep banks and fork scratch stay the engine's; the join arrays do not
+    w.node = reinterpret_cast<uint64_t*>(p + SCR_NODE);
+    w.dst = reinterpret_cast<uint64_t*>(p + SCR_DST);
+    w.ev_slot = reinterpret_cast<uint32_t*>(p + SCR_EV_SLOT);
+    w.complex_ = reinterpret_cast<uint32_t*>(p + SCR_COMPLEX);
+    w.counters = reinterpret_cast<unsigned int*>(p + SCR_COUNTERS);
+    w.counters_next = w.counters + C_COUNT;
+    return join_launch(e, w, true, n, d_recs, d_payloads, pitch, now_ms, d_status);
 }
 
 static uint32_t pop_blocks(const dj_engine* e) {

@@ -106,6 +106,12 @@ class Engine:
         self._check(self.L.dj_join_batch(self.h, n, d_recs.data_ptr(), d_payloads.data_ptr(), int(pitch), int(now_ms),
                                          d_status.data_ptr()))
 
+    def join_batch_static_dev(self, n, d_recs, d_payloads, pitch, now_ms, d_status):
+        """dj_join_batch_static: the same pass with its work arrays in the library's static device array
+        (n <= capi.DJ_STATIC_JOIN_MAX; allocates nothing)."""
+        self._check(self.L.dj_join_batch_static(self.h, n, d_recs.data_ptr(), d_payloads.data_ptr(), int(pitch),
+                                                int(now_ms), d_status.data_ptr()))
+
     def sweep_dev(self, now_ms, cap_conts, cap_positions, d_conts, d_lens, d_mws, d_payloads, d_result, h_result=None):
         self._check(self.L.dj_sweep(self.h, int(now_ms), int(cap_conts), int(cap_positions), d_conts.data_ptr(),
                                     d_lens.data_ptr() if d_lens is not None else None,

@@ -192,6 +192,19 @@ int dj_fork_batch(dj_engine* e, uint32_t n, const dj_fork_rec* d_recs, int32_t* 
 int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs,
                   const uint8_t* d_payloads, uint64_t pitch, uint64_t now_ms, int32_t* d_status);
 
+/* dj_join_batch for callers that must not allocate (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same results, same
+ * kernels as dj_join_batch; the per-batch work arrays (link words, destinations, event-to-slot map, list of
+ * long chains, counters: 24 bytes per event) live in a device array of the library's code object instead of
+ * memory the engine allocated, 1.5 MiB per GPU that stays until the process ends.  Limit: n <=
+ * DJ_STATIC_JOIN_MAX events per call (DJ_E_TOO_LARGE beyond).  The call itself allocates and frees nothing
+ * (no hipMalloc, hipFree or allocating library routine).  Every engine on one GPU shares that GPU's array:
+ * two such calls that overlap on one GPU (two engines, i.e. two streams) race; calls on one engine are
+ * ordered by its stream.  Barriers with very many events in one batch always take the serial kernel here. */
+#define DJ_STATIC_JOIN_MAX 65536u
+int dj_join_batch_static(dj_engine* e, uint32_t n, const dj_join_rec* d_recs,
+                         const uint8_t* d_payloads, uint64_t pitch, uint64_t now_ms, int32_t* d_status);
+
 /* redis/all-publish-messages (redis.clj:283-289): pop every barrier whose primary score is
  * <= now_ms; the backup entry stays.  Writes fp, publish_at (and the metadata snapshot) of at
  * most cap_conts barriers; d_result->more says whether some were left.  Order unspecified. */
