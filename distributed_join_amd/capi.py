@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdj_engine.so")
+# DJ_ENGINE_LIB: another build of the same library (A/B timing of two builds in one GPU session)
+LIB_PATH = os.environ.get("DJ_ENGINE_LIB") or os.path.join(_HERE, "libdj_engine.so")
 
 # ---- constants of include/dj_engine.h ---------------------------------------------
 DJ_OK = 0
@@ -57,7 +58,8 @@ SYMBOLS = ["dj_create", "dj_destroy", "dj_last_error", "dj_sync", "dj_stream", "
            "dj_ack_batch", "dj_recover", "dj_snapshot_one", "dj_store_in_publish_queue",
            "dj_queue_scores", "dj_get_stats", "dj_owner_of", "dj_partition_joins", "dj_profile_enable",
            "dj_profile_read", "dj_compact", "dj_set_hot_path", "dj_checkpoint_save", "dj_checkpoint_load",
-           "dj_get_config", "dj_fetch_long", "dj_join_batch_static"]
+           "dj_get_config", "dj_fetch_long", "dj_join_batch_static",
+           "dj_set_sweep_path"]
 # include/dj_batcher.h
 BATCHER_SYMBOLS = ["dj_batcher_create", "dj_batcher_destroy", "dj_batcher_set_clock", "dj_batcher_join",
                    "dj_batcher_fork", "dj_batcher_join_wait", "dj_batcher_fork_wait", "dj_batcher_run",
@@ -116,8 +118,9 @@ def load():
     L.dj_fork_batch.argtypes = [vp, u32, vp, vp]
     L.dj_join_batch.restype = i32
     L.dj_join_batch.argtypes = [vp, u32, vp, vp, u64, u64, vp]
-    L.dj_join_batch_static.restype = i32
-    L.dj_join_batch_static.argtypes = [vp, u32, vp, vp, u64, u64, vp]
+    if not os.environ.get("DJ_ENGINE_LIB") or hasattr(L, "dj_join_batch_static"):
+        L.dj_join_batch_static.restype = i32
+        L.dj_join_batch_static.argtypes = [vp, u32, vp, vp, u64, u64, vp]
     L.dj_pop_due.restype = i32
     L.dj_pop_due.argtypes = [vp, u64, u32, vp, vp, vp]
     L.dj_sweep.restype = i32
@@ -140,6 +143,9 @@ def load():
     L.dj_partition_joins.argtypes = [vp, u32, u32, vp, vp, u64, vp, vp, vp, vp, vp]
     L.dj_set_hot_path.restype = i32
     L.dj_set_hot_path.argtypes = [vp, i32]
+    if not os.environ.get("DJ_ENGINE_LIB") or hasattr(L, "dj_set_sweep_path"):     # an older build under A/B lacks it
+        L.dj_set_sweep_path.restype = i32
+        L.dj_set_sweep_path.argtypes = [vp, i32]
     L.dj_checkpoint_save.restype = i32
     L.dj_checkpoint_save.argtypes = [vp, ctypes.c_char_p]
     L.dj_checkpoint_load.restype = i32

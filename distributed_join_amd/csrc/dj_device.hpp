@@ -46,6 +46,8 @@ constexpr uint32_t RETRY_NIL = 0xFFu;  // retry counter absent
 constexpr int NUM_CLASSES = 11;        // 1, 2, 4 ... 1024 positions
 constexpr uint64_t NODST = ~0ull;
 constexpr uint32_t CONT_VOID = DJ_CONT_VOID;  // descriptor index allocated but not popped
+constexpr uint32_t READY_SHARDS = 256;        // sub-lists of the ready list, each with a counter on a line of its own
+constexpr uint32_t READY_PAD = 32;            // counters are READY_PAD words apart (128 bytes)
 
 struct __attribute__((aligned(64))) Slot {
     uint64_t fp_lo, fp_hi;
@@ -115,6 +117,19 @@ struct Table {
     unsigned int* oring_head;         // [OVF_CLASSES]
     unsigned int* oring_tail;
     unsigned int* oring_tail_snap;    // tails before the current join batch's copy pass: pops stop here
+    // Ready list (the device-side form of "the primary queue, ordered by score"): a join batch appends the slot
+    // of every barrier it completes (queued at now); the next sweep drains the list instead of scanning q[].
+    // Every OTHER writer of a primary score (fork deadlines, max-wait dates, re-queues) lowers *due_min
+    // instead; a sweep scans q[] only when its now has reached that bound (or the list overflowed / was
+    // invalidated), and the scan recomputes the bound.  The list may hold stale or repeated slots: a pop is
+    // decided by q[slot] alone.
+    uint32_t* ready;                  // [READY_SHARDS][ready_shard_cap]
+    unsigned int* ready_n;            // [READY_SHARDS * READY_PAD] entries appended per shard (may run past the cap)
+    unsigned int* ready_ovf;          // != 0: the list is incomplete, the next sweep scans
+    unsigned long long* due_min;      // lower bound of the primary scores that are in no list (the bank the next sweep reads)
+    uint32_t ready_shard_cap;
+    uint32_t ready_on;                // 0: no list and no bound are kept, every sweep scans (small tables: the scan is cheap
+                                      // and hands the gather pass its barriers in slot order)
     uint32_t max_message;             // longest message accepted, >= stride
     uint32_t stride;
     uint32_t fork_pmd;                // 1: barriers are forked with META_PMD set (recent joins were mostly not full rows
@@ -139,6 +154,8 @@ struct Work {
                                   // [4..7] how many of the batch's first 4 x 64 events store a {len, max-wait} word
     unsigned long long* sweep;    // S_* below, bank of the current sweep
     unsigned long long* sweep_next;
+    unsigned long long* due_cur;  // scan bound the current sweep reads (what Table::due_min pointed to since the last one)
+    unsigned long long* due_next; // scan bound the current sweep leaves for the next one
     // hot-barrier path (barriers with long chains), see the cx_* kernels
     uint32_t* cx_keys;            // [CX_HASH] slab of a hot barrier, 0 = empty
     uint32_t* cx_val;             // [CX_HASH] its index in complex_[]
@@ -172,7 +189,7 @@ constexpr uint32_t CX_POOL = 1u << 24; // positions of all of them together (the
 constexpr uint32_t IDX_NONE = 0xFFFFFFFFu;
 // sweep scratch: S_CURSOR packs both output cursors so a block takes its output range with one
 // atomic: continuations in the low 31 bits, positions above (positions * 64 B <= arena <= 256 GiB)
-enum { S_CURSOR = 0, S_MORE = 1, S_COUNT = 2 };
+enum { S_CURSOR = 0, S_MORE = 1, S_SCANNED = 2, S_COUNT = 4 };
 constexpr int CURSOR_SHIFT = 31;
 constexpr unsigned long long CURSOR_CONT_MASK = (1ull << CURSOR_SHIFT) - 1;
 
@@ -218,6 +235,40 @@ __device__ inline uint32_t wave_append(unsigned int* counter, bool pred) {
     if ((int)lane == leader) base = a_add(counter, (unsigned int)__popcll(m));
     base = __shfl(base, leader);
     return pred ? base + (uint32_t)__popcll(m & ((1ull << lane) - 1)) : 0xFFFFFFFFu;
+}
+
+// A primary score written without a ready-list entry: keep the sweep's scan bound below it.  Most callers see
+// a bound that is already low enough and issue no atomic.
+__device__ inline void note_queue_date(const Table& t, uint64_t at) {
+    if (t.ready_on && at < a_load(t.due_min)) __hip_atomic_fetch_min(t.due_min, (unsigned long long)at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Append the slots of lanes with pred to the ready list: one atomic per wave, on the counter of the shard
+// `shard`.  Must be reached by the wave in converged control flow.
+__device__ inline void ready_append_wave(const Table& t, bool pred, uint32_t slot, uint32_t shard) {
+    if (!t.ready_on) return;
+    const uint64_t m = __ballot(pred);
+    if (m == 0) return;
+    shard &= READY_SHARDS - 1;
+    const uint32_t lane = lane_id();
+    const int leader = __ffsll((unsigned long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = a_add(&t.ready_n[shard * READY_PAD], (unsigned int)__popcll(m));
+    base = __shfl(base, leader);
+    if (pred) {
+        const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        if (at < t.ready_shard_cap) t.ready[(size_t)shard * t.ready_shard_cap + at] = slot;
+        else a_store(t.ready_ovf, 1u);
+    }
+}
+
+// one entry from one thread (rare paths)
+__device__ inline void ready_append_one(const Table& t, uint32_t slot, uint32_t shard) {
+    if (!t.ready_on) return;
+    shard &= READY_SHARDS - 1;
+    const uint32_t at = a_add(&t.ready_n[shard * READY_PAD], 1u);
+    if (at < t.ready_shard_cap) t.ready[(size_t)shard * t.ready_shard_cap + at] = slot;
+    else a_store(t.ready_ovf, 1u);
 }
 
 // ---- probing -----------------------------------------------------------------------

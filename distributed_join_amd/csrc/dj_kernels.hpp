@@ -71,35 +71,50 @@ __global__ void __launch_bounds__(FORK_APPLY_BLOCK) fork_apply_kernel(Table t, W
     // a barrier that is reset gives its long-message blocks back (not when the reset is refused below)
     if (long_on) wave_release_long_each(t, had_long && !(need && fresh == 0), old_slab, k_old, 0, old_count);
     block_slab_free(t, need && fresh != 0, k_old, old_slab, lds);
-    if (!active) return;
     // phase C (per lane)
+    __shared__ unsigned long long due_lo;
+    if (threadIdx.x == 0) due_lo = NQ;
+    __syncthreads();
+    bool ok = active;
     uint32_t slab = old_slab;
-    if (need) {
+    if (active && need) {
         if (fresh == 0) {
             // engine limit, no counterpart in the reference: report it and leave the table as it was
             status[i] = DJ_FORK_NO_SPACE;
             sl->chain = 0;
             if (!(sl->meta & META_HAS) && t.q[s] == Q_NONE) clear_slot(t, s);
-            return;
+            ok = false;
+        } else {
+            slab = fresh;
         }
-        slab = fresh;
     }
-    if (r.count > 64) {
-        uint64_t* bm = slab_bitmap(t, slab);
-        for (uint32_t j = 0; j < (class_positions(k_new) >> 6); ++j) bm[j] = 0;
+    if (ok) {
+        if (r.count > 64) {
+            uint64_t* bm = slab_bitmap(t, slab);
+            for (uint32_t j = 0; j < (class_positions(k_new) >> 6); ++j) bm[j] = 0;
+        }
+        // pre-filled words are what a barrier without META_PMD relies on; with long messages enabled the words of
+        // absent positions are read as well (none may look like a long message)
+        if (!t.fork_pmd || long_on) fill_posmeta_default(t, slab, k_new);
+        sl->count = r.count;                                  // SET <id>:metadata
+        sl->meta = meta_pack(true, RETRY_NIL, RETRY_NIL) | (t.fork_pmd ? META_PMD : 0u);
+        sl->slab = slab;
+        sl->chain = 0;
+        sl->deadline = r.deadline_ms;
+        sl->join_ts = 0;                                      // DEL <id>:join-ts
+        sl->join_ts_read = 0;                                 // DEL <id>:join-ts-read
+        sl->bits = 0;                                         // DEL <id>
+        t.q[s] = r.deadline_ms;                               // ZREM both, then ZADD both (redis.clj:257-258)
     }
-    // pre-filled words are what a barrier without META_PMD relies on; with long messages enabled the words of
-    // absent positions are read as well (none may look like a long message)
-    if (!t.fork_pmd || long_on) fill_posmeta_default(t, slab, k_new);
-    sl->count = r.count;                                  // SET <id>:metadata
-    sl->meta = meta_pack(true, RETRY_NIL, RETRY_NIL) | (t.fork_pmd ? META_PMD : 0u);
-    sl->slab = slab;
-    sl->chain = 0;
-    sl->deadline = r.deadline_ms;
-    sl->join_ts = 0;                                      // DEL <id>:join-ts
-    sl->join_ts_read = 0;                                 // DEL <id>:join-ts-read
-    sl->bits = 0;                                         // DEL <id>
-    t.q[s] = r.deadline_ms;                               // ZREM both, then ZADD both (redis.clj:257-258)
+    // the sweep's scan bound must not be above any deadline queued here: one atomic per block at most
+    unsigned long long lo = ok ? r.deadline_ms : NQ;
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = ((unsigned long long)__shfl_xor((uint32_t)(lo >> 32), off) << 32) | __shfl_xor((uint32_t)lo, off);
+        if (o < lo) lo = o;
+    }
+    if (t.ready_on && (threadIdx.x & 63) == 0 && lo != NQ) atomicMin(&due_lo, lo);
+    __syncthreads();
+    if (threadIdx.x == 0 && due_lo != NQ) note_queue_date(t, due_lo);
 }
 
 // =====================================================================================
@@ -284,11 +299,12 @@ __device__ inline int32_t replay_one(const Table& t, uint64_t s, uint32_t slab, 
 constexpr int CHAIN_REG = 8, CHAIN_REG_WIDE = 16;
 
 template <int CR>
-__global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint32_t n, uint64_t now, int32_t* status) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CR <= 8 ? 8 : 4)))
+join_resolve_kernel(Table t, Work w, uint32_t n, uint64_t now, int32_t* status) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     // block pops of the copy pass stop at the tails as they are now (nothing touches these rings here)
     if (blockIdx.x == 0 && threadIdx.x < OVF_CLASSES) t.oring_tail_snap[threadIdx.x] = t.oring_tail[threadIdx.x];
-    bool is_complex = false, mid = false;
+    bool is_complex = false, mid = false, completed = false;
     uint32_t s = tid < n ? w.ev_slot[tid] : 0xFFFFFFFFu;
     // The event that linked FIRST (it found the chain empty) resolves the barrier: it knows that from
     // its own link word, so every other event leaves without touching the table again.
@@ -351,10 +367,11 @@ __global__ void __launch_bounds__(256) join_resolve_kernel(Table t, Work w, uint
             store_ts_bits(sl, now, count > 64 ? (uint64_t)r.arrived : r.bits);   // SET <id>:join-ts, redis.clj:136
             sl->chain = 0;
             if (info.y & META_HOT) sl->meta = info.y & ~META_HOT; // a short chain: not hot any more
-            if (r.enq) t.q[s] = now;                    // ZADD both at now, redis.clj:257-258
-            else if (r.pa_dirty) t.q[s] = r.pa;         // ZADD both at the nearer date, redis.clj:270-271
+            if (r.enq) { t.q[s] = now; completed = true; }               // ZADD both at now, redis.clj:257-258
+            else if (r.pa_dirty) { t.q[s] = r.pa; note_queue_date(t, r.pa); }   // ZADD both at the nearer date, redis.clj:270-271
         }
     }
+    ready_append_wave(t, completed, s, tid >> 6);
     uint32_t at = wave_append(&w.counters[C_COMPLEX], is_complex);
     if (is_complex) w.complex_[at] = s;
     if (CR > CHAIN_REG && ((tid >> 6) & 7) == 0) {      // one wave in eight reports how many such chains it replayed
@@ -548,8 +565,8 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
             sl->bits = count > 64 ? (uint64_t)arrived : bits0;
             sl->join_ts = now;
             sl->chain = 0;
-            if (T != IDX_NONE) t.q[s] = now;
-            else if (pa_pre != NQ && at_min < pa_pre) t.q[s] = at_min;
+            if (T != IDX_NONE) { t.q[s] = now; ready_append_one(t, s, blockIdx.x); }
+            else if (pa_pre != NQ && at_min < pa_pre) { t.q[s] = at_min; note_queue_date(t, at_min); }
         }
         __syncthreads();
     }
@@ -762,8 +779,8 @@ __global__ void __launch_bounds__(64) cx_finalize_kernel(Table t, Work w, uint64
             sl->join_ts = now;
             sl->chain = 0;
             // events before T wait (store-nearest, redis.clj:269-271); from T on the barrier is queued at now
-            if (T != IDX_NONE) t.q[s] = now;
-            else if (pa_pre != NQ && at_min < pa_pre) t.q[s] = at_min;
+            if (T != IDX_NONE) { t.q[s] = now; ready_append_one(t, s, blockIdx.x); }
+            else if (pa_pre != NQ && at_min < pa_pre) { t.q[s] = at_min; note_queue_date(t, at_min); }
             const uint32_t events = w.cx_cnt[c];
             if (events > longest) longest = events;
             if (events <= CHAIN_REG_WIDE) ++n_mid;
@@ -980,24 +997,119 @@ __device__ inline void fill_cont(dj_cont* c, const Slot& sl, uint64_t now, uint6
     }
 }
 
-// One pass over q[]: every slot with q <= now (in the primary queue, score <= now) is popped
-// (ZRANGEBYSCORE + ZREMRANGEBYSCORE 0 now).  A block scans chunks of 256 * POP_ITEMS queue words
-// with POP_ITEMS loads in flight per thread and collects the due slots in a list in LDS; the list
-// is then worked off one entry per thread (one slot read each, descriptors written to consecutive
-// indices).  Output indices come from a block-wide prefix sum and ONE atomic on the packed cursor
-// word per 256 entries.  The cursors are raw (they may run past the caps); the gather pass (or
-// finish_result_kernel) publishes the clamped dj_sweep_result.
+// The pop of a sweep: every slot with q <= now (in the primary queue, score <= now) is popped
+// (ZRANGEBYSCORE + ZREMRANGEBYSCORE 0 now).  Two forms, picked on the device, the same for every block:
+//   drain  now has not reached the scan bound *due_cur: whatever is due sits in the ready list (barriers
+//          that join batches completed since the last sweep).  A block takes whole shards of the list; an
+//          entry is popped when its queue word says so, decided by a compare-and-swap (the list may name a
+//          slot twice, or a slot whose barrier was re-forked or deleted since).
+//   scan   one pass over q[].  A block scans chunks of 256 * POP_ITEMS queue words with POP_ITEMS loads
+//          in flight per thread and collects the due slots in a list in LDS.  The pass also recomputes the
+//          bound: the smallest primary score that stays queued goes to *due_next.
+// Either way the due slots are then worked off one entry per thread (one slot read each, descriptors
+// written to consecutive indices).  Output indices come from a block-wide prefix sum and ONE atomic on the
+// packed cursor word per 256 entries.  The cursors are raw (they may run past the caps); the gather pass
+// (or finish_result_kernel) publishes the clamped dj_sweep_result.
 constexpr int POP_ITEMS = 16;
 
-__global__ void __launch_bounds__(256) pop_due_kernel(Table t, Work w, uint64_t now, uint32_t cap_conts,
+struct PopShared {
+    uint32_t wave_c[4], wave_p[4];
+    unsigned long long base_s;
+};
+
+// One round of up to 256 due slots, one per thread (has).  popped: the queue word already carries Q_POPPED
+// (drain form); a barrier that does not fit the caller's buffers is then put back.
+__device__ inline void pop_emit_round(const Table& t, const Work& w, PopShared& sh, bool has, uint64_t s, uint64_t pa,
+                                      bool popped, uint64_t now, uint32_t cap_conts, uint64_t cap_pos, int alloc_pos,
+                                      dj_cont* conts) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t cnt = 0;
+    Slot sl;
+    if (has) {
+        sl = t.slots[s];
+        cnt = (alloc_pos && (sl.meta & META_HAS)) ? sl.count : 0;
+    }
+    const uint32_t incl_c = wave_incl_scan(has ? 1u : 0u), incl_p = wave_incl_scan(cnt);
+    if (lane == 63) { sh.wave_c[wv] = incl_c; sh.wave_p[wv] = incl_p; }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long tc = sh.wave_c[0] + sh.wave_c[1] + sh.wave_c[2] + sh.wave_c[3];
+        const unsigned long long tp = sh.wave_p[0] + sh.wave_p[1] + sh.wave_p[2] + sh.wave_p[3];
+        sh.base_s = tc ? a_add(&w.sweep[S_CURSOR], tc | (tp << CURSOR_SHIFT)) : 0ull;
+    }
+    __syncthreads();
+    uint32_t c_idx = (uint32_t)(sh.base_s & CURSOR_CONT_MASK) + incl_c - 1;
+    uint64_t p_idx = (sh.base_s >> CURSOR_SHIFT) + incl_p - cnt;
+    for (uint32_t v = 0; v < wv; ++v) { c_idx += sh.wave_c[v]; p_idx += sh.wave_p[v]; }
+    if (has) {
+        bool fits = true;
+        if (c_idx >= cap_conts) {
+            fits = false;
+        } else if (alloc_pos && p_idx + cnt > cap_pos) {
+            fits = false;
+            dj_cont v = {};                      // index taken, barrier stays queued
+            v.flags = CONT_VOID;
+            conts[c_idx] = v;
+            w.cont_slot[c_idx] = 0xFFFFFFFFu;
+        }
+        if (fits) {
+            if (!popped) t.q[s] = pa | Q_POPPED;     // popped; the backup entry stays (redis.clj:288)
+            fill_cont(&conts[c_idx], sl, now, pa, p_idx, s + 1);
+            w.cont_slot[c_idx] = (uint32_t)s;
+        } else {
+            w.sweep[S_MORE] = 1;
+            if (popped) t.q[s] = pa;
+            // still due: the next sweep has to scan for it
+            if (pa < a_load(w.due_next)) __hip_atomic_fetch_min(w.due_next, (unsigned long long)pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+}
+
+// drain form (launched only by engines that keep the ready list)
+__global__ void __launch_bounds__(256) pop_ready_kernel(Table t, Work w, uint64_t now, uint32_t cap_conts,
+                                                        uint64_t cap_pos, int alloc_pos, dj_cont* conts) {
+    __shared__ PopShared sh;
+    const uint32_t tid = threadIdx.x;
+    if (now >= *w.due_cur || *t.ready_ovf != 0) return;      // the scan's turn; nobody writes either word during a sweep's pop kernels
+    // block b: shard b mod READY_SHARDS, every (gridDim.x / READY_SHARDS)-th piece of 256 entries of it
+    const uint32_t shard = blockIdx.x & (READY_SHARDS - 1), per_shard = gridDim.x / READY_SHARDS;    // grid: a multiple of READY_SHARDS
+    const uint32_t filled = t.ready_n[shard * READY_PAD];
+    const uint32_t ln = filled < t.ready_shard_cap ? filled : t.ready_shard_cap;
+    const uint32_t* entries = t.ready + (size_t)shard * t.ready_shard_cap;
+    for (uint32_t r = (blockIdx.x / READY_SHARDS) * 256; r < ln; r += per_shard * 256) {     // uniform across the block
+        const uint32_t e = r + tid;
+        bool has = e < ln;
+        uint64_t s = 0, pa = NQ;
+        if (has) {
+            s = entries[e];
+            pa = a_load(&t.q[s]);
+            if (pa <= now) {
+                has = a_cas(&t.q[s], pa, pa | Q_POPPED);       // false: another entry of the same slot got it
+            } else {
+                has = false;
+                // queued for later (a re-fork, or a caller whose clock went back): the bound must cover it
+                if (!(pa >> 63) && pa < a_load(w.due_next))
+                    __hip_atomic_fetch_min(w.due_next, (unsigned long long)pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        pop_emit_round(t, w, sh, has, s, pa, true, now, cap_conts, cap_pos, alloc_pos, conts);
+    }
+}
+
+// scan form; TRACK: the engine keeps a ready list, so the pass also has to recompute the scan bound
+template <bool TRACK>
+__device__ inline void pop_due_body(const Table& t, const Work& w, uint64_t now, uint32_t cap_conts,
                                                       uint64_t cap_pos, int alloc_pos, dj_cont* conts) {
     __shared__ uint16_t list[256 * POP_ITEMS];     // offsets of the chunk's due slots
     __shared__ uint32_t list_n;
-    __shared__ uint32_t wave_c[4], wave_p[4];
-    __shared__ unsigned long long base_s;
+    __shared__ PopShared sh;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    if (TRACK && now < *w.due_cur && *t.ready_ovf == 0) return;           // the ready list held everything that is due
+    if (TRACK && blockIdx.x == 0 && tid == 0) w.sweep[S_SCANNED] = 1;
     const uint64_t nslots = t.mask + 1;
     const uint64_t chunk = 256ull * POP_ITEMS;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint64_t later = NQ;                             // smallest primary score beyond now that this thread saw
     for (uint64_t cb = blockIdx.x * chunk; cb < nslots; cb += (uint64_t)gridDim.x * chunk) {
         if (tid == 0) list_n = 0;
         __syncthreads();
@@ -1005,7 +1117,9 @@ __global__ void __launch_bounds__(256) pop_due_kernel(Table t, Work w, uint64_t 
 #pragma unroll
         for (int j = 0; j < POP_ITEMS; ++j) {
             const uint64_t s = cb + (uint64_t)j * 256 + tid;
-            if (s < nslots && t.q[s] <= now) due_mask |= 1u << j;
+            const uint64_t qv = s < nslots ? t.q[s] : NQ;
+            if (qv <= now) due_mask |= 1u << j;
+            else if (TRACK && qv < later) later = qv;     // popped and absent entries have bit 63 set: above every score
         }
         const uint32_t nd = (uint32_t)__popc(due_mask);
         const uint32_t incl = wave_incl_scan(nd);
@@ -1024,48 +1138,40 @@ __global__ void __launch_bounds__(256) pop_due_kernel(Table t, Work w, uint64_t 
             const uint32_t e = r + tid;
             const bool has = e < ln;
             uint64_t s = 0, pa = 0;
-            uint32_t cnt = 0;
-            Slot sl;
             if (has) {
                 s = cb + list[e];
-                sl = t.slots[s];
                 pa = t.q[s];
-                cnt = (alloc_pos && (sl.meta & META_HAS)) ? sl.count : 0;
             }
-            const uint32_t incl_c = wave_incl_scan(has ? 1u : 0u), incl_p = wave_incl_scan(cnt);
-            if (lane == 63) { wave_c[wv] = incl_c; wave_p[wv] = incl_p; }
-            __syncthreads();
-            if (tid == 0) {
-                const unsigned long long tc = wave_c[0] + wave_c[1] + wave_c[2] + wave_c[3];
-                const unsigned long long tp = wave_p[0] + wave_p[1] + wave_p[2] + wave_p[3];
-                base_s = a_add(&w.sweep[S_CURSOR], tc | (tp << CURSOR_SHIFT));
-            }
-            __syncthreads();
-            uint32_t c_idx = (uint32_t)(base_s & CURSOR_CONT_MASK) + incl_c - 1;
-            uint64_t p_idx = (base_s >> CURSOR_SHIFT) + incl_p - cnt;
-            for (uint32_t v = 0; v < wv; ++v) { c_idx += wave_c[v]; p_idx += wave_p[v]; }
-            if (has) {
-                if (c_idx >= cap_conts) {
-                    w.sweep[S_MORE] = 1;
-                } else if (alloc_pos && p_idx + cnt > cap_pos) {
-                    w.sweep[S_MORE] = 1;
-                    dj_cont v = {};                      // index taken, barrier stays queued
-                    v.flags = CONT_VOID;
-                    conts[c_idx] = v;
-                    w.cont_slot[c_idx] = 0xFFFFFFFFu;
-                } else {
-                    t.q[s] = pa | Q_POPPED;              // popped; the backup entry stays (redis.clj:288)
-                    fill_cont(&conts[c_idx], sl, now, pa, p_idx, s + 1);
-                    w.cont_slot[c_idx] = (uint32_t)s;
-                }
-            }
-            __syncthreads();
+            pop_emit_round(t, w, sh, has, s, pa, false, now, cap_conts, cap_pos, alloc_pos, conts);
         }
     }
+    if (!TRACK) return;                              // nobody reads the bound
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t o = ((uint64_t)__shfl_xor((uint32_t)(later >> 32), off) << 32) | __shfl_xor((uint32_t)later, off);
+        if (o < later) later = o;
+    }
+    if (lane == 0 && !(later >> 63) && later < a_load(w.due_next))
+        __hip_atomic_fetch_min(w.due_next, (unsigned long long)later, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// clamp the raw cursors into the caller-visible result; resets the other sweep bank
-__device__ inline void publish_result(const Work& w, dj_sweep_result* res, uint32_t cap_conts, uint64_t cap_pos) {
+// (at most 80 scalar registers: from 82 on a compute unit admits seven blocks of 256 threads instead of eight)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8), amdgpu_num_sgpr(80)))
+pop_due_kernel(Table t, Work w, uint64_t now, uint32_t cap_conts, uint64_t cap_pos, int alloc_pos, dj_cont* conts) {
+    pop_due_body<false>(t, w, now, cap_conts, cap_pos, alloc_pos, conts);
+}
+
+__global__ void __launch_bounds__(256) pop_due_track_kernel(Table t, Work w, uint64_t now, uint32_t cap_conts,
+                                                            uint64_t cap_pos, int alloc_pos, dj_cont* conts) {
+    pop_due_body<true>(t, w, now, cap_conts, cap_pos, alloc_pos, conts);
+}
+
+// clamp the raw cursors into the caller-visible result; resets the other sweep bank, hands the scan bound to
+// the next sweep and empties the ready list.  Called by all threads of ONE block after the pop kernels have
+// finished.
+__device__ inline void publish_result(const Table& t, const Work& w, dj_sweep_result* res, uint32_t cap_conts, uint64_t cap_pos) {
+    if (t.ready_on)
+        for (uint32_t k = threadIdx.x; k < READY_SHARDS; k += blockDim.x) t.ready_n[k * READY_PAD] = 0;
+    if (threadIdx.x != 0) return;
     const unsigned long long cur = w.sweep[S_CURSOR];
     const unsigned long long nc = cur & CURSOR_CONT_MASK, np = cur >> CURSOR_SHIFT;
     res->n_conts = nc > cap_conts ? cap_conts : (uint32_t)nc;
@@ -1073,10 +1179,16 @@ __device__ inline void publish_result(const Work& w, dj_sweep_result* res, uint3
     res->more = w.sweep[S_MORE] ? 1u : 0u;
     w.sweep_next[S_CURSOR] = 0;
     w.sweep_next[S_MORE] = 0;
+    if (!t.ready_on) return;
+    w.sweep_next[S_SCANNED] = 0;
+    // a scan has recomputed the bound into *due_next; a drain leaves what is queued for later where it was
+    if (!w.sweep[S_SCANNED] && *w.due_cur < *w.due_next) *w.due_next = *w.due_cur;
+    *w.due_cur = NQ;                                 // the bank after next starts empty
+    *t.ready_ovf = 0;
 }
 
-__global__ void finish_result_kernel(Work w, dj_sweep_result* res, uint32_t cap_conts, uint64_t cap_pos) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) publish_result(w, res, cap_conts, cap_pos);
+__global__ void finish_result_kernel(Table t, Work w, dj_sweep_result* res, uint32_t cap_conts, uint64_t cap_pos) {
+    if (blockIdx.x == 0) publish_result(t, w, res, cap_conts, cap_pos);
 }
 
 // redis/all-joins for n continuations.  GS lanes work on one continuation, 64 / GS continuations per
@@ -1130,7 +1242,9 @@ __device__ inline void gather_body(const Table& t, const Work& w, const dj_cont*
 // the sweep's result block) or for n_fixed listed continuations.  Lanes per continuation: after a sweep
 // from what was actually popped (16-byte chunks per continuation on average: whole waves from 96 on,
 // measured on counts 4..64 x 64..1024 bytes), else the caller's choice.
-__global__ void __launch_bounds__(256) gather_kernel(Table t, Work w, const dj_cont* conts, int from_sweep,
+// (at most 80 scalar registers: from 82 on a compute unit admits seven blocks of 256 threads instead of eight)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(80)))
+gather_kernel(Table t, Work w, const dj_cont* conts, int from_sweep,
                                                      uint32_t n_fixed, uint32_t cap_conts, uint64_t cap_pos,
                                                      int update_ts, uint32_t* lens, uint32_t* max_waits,
                                                      uint8_t* payloads, dj_sweep_result* res, int gs_fixed) {
@@ -1146,7 +1260,7 @@ __global__ void __launch_bounds__(256) gather_kernel(Table t, Work w, const dj_c
     if (gs == 64) gather_body<64>(t, w, conts, n, update_ts, lens, max_waits, payloads);
     else if (gs == 16) gather_body<16>(t, w, conts, n, update_ts, lens, max_waits, payloads);
     else gather_body<8>(t, w, conts, n, update_ts, lens, max_waits, payloads);
-    if (from_sweep && res && blockIdx.x == 0 && threadIdx.x == 0) publish_result(w, res, cap_conts, cap_pos);
+    if (from_sweep && res && blockIdx.x == 0) publish_result(t, w, res, cap_conts, cap_pos);
 }
 
 // =====================================================================================
@@ -1163,6 +1277,7 @@ __device__ inline bool complete_decide(const Table& t, uint64_t s, uint64_t now)
     // reset-publish: both retry counters dropped, :publish-retry-cnt 0, re-queued at now
     sl->meta = meta_pack(sl->meta & META_HAS, 0, RETRY_NIL) | (sl->meta & (META_OVF | META_PMD));
     t.q[s] = now;
+    note_queue_date(t, now);
     return false;
 }
 
@@ -1181,6 +1296,7 @@ __device__ inline void retry_requeue(const Table& t, uint64_t s, bool timeout, u
     if (timeout) rt = cnt + 1; else rp = cnt + 1;
     t.slots[s].meta = meta_pack(true, rp, rt) | (t.slots[s].meta & (META_OVF | META_PMD));
     t.q[s] = now;
+    note_queue_date(t, now);
 }
 
 constexpr int ACK_BLOCK = 1024;
@@ -1427,6 +1543,7 @@ __global__ void store_in_queue_one_kernel(Table t, uint64_t lo, uint64_t hi, uin
         sl->deadline = 0; sl->join_ts = 0; sl->join_ts_read = 0; sl->bits = 0;
     }
     t.q[s] = at;
+    note_queue_date(t, at);
     *err = 0;
 }
 

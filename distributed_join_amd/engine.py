@@ -281,6 +281,11 @@ class Engine:
         register replay of short chains, 0 / 1 the 8-event one (same results in every mode)."""
         self._check(self.L.dj_set_hot_path(self.h, int(mode)))
 
+    def set_sweep_path(self, mode):
+        """-1 by table size, 0 every sweep scans the queue words, 1 sweeps drain the ready list that join
+        batches fill (same results)."""
+        self._check(self.L.dj_set_sweep_path(self.h, int(mode)))
+
     def checkpoint_save(self, path):
         """Write the whole barrier state to a file (waits for the stream)."""
         self._check(self.L.dj_checkpoint_save(self.h, str(path).encode()))

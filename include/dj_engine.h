@@ -300,6 +300,14 @@ int dj_checkpoint_load(dj_engine* e, const char* path);
  * counterpart. */
 int dj_set_hot_path(dj_engine* e, int mode);
 
+/* How a sweep finds what is due.  The reference pops a sorted set by score (redis.clj:283-289), which costs
+ * what is due, not what is stored.  The engine has two forms with identical results: a scan of the queue
+ * words (8 bytes per table slot) and a ready list that join batches append completed barriers to, with a
+ * lower bound of every other queue date that tells a sweep when a scan is needed after all (deadlines,
+ * max-waits, re-queues).  mode -1: by table size (the list from 2^24 slots), 0: always scan, 1: keep the
+ * list.  No reference counterpart. */
+int dj_set_sweep_path(dj_engine* e, int mode);
+
 /* ---- per-kernel timing (measurement aid; no counterpart in the reference) ---------- */
 /* Kernel ids for dj_profile_read.  With profiling enabled every launch of these kernels is
  * bracketed by a pair of HIP events on the engine's stream. */

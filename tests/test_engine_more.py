@@ -11,9 +11,13 @@ pytestmark = pytest.mark.gpu
 T0 = 1_700_000_000_000
 
 
-def _engine(**kw):
+def _engine(sweep_mode=1, **kw):
+    """sweep_mode 1: sweeps drain the ready list whatever the table size (the op-log tests of
+    test_engine_parity.py run both forms); -1 leaves the choice to the engine."""
     from distributed_join_amd.engine import Engine
-    return Engine(**kw)
+    e = Engine(**kw)
+    e.set_sweep_path(sweep_mode)
+    return e
 
 
 def test_sweep_caps_leave_the_rest_queued(oracle_lib):

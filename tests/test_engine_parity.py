@@ -15,6 +15,14 @@ from tests.parity import ParityDriver, payload_bytes
 
 pytestmark = pytest.mark.gpu
 T0 = 1_700_000_000_000
+SWEEP_MODE = [0]
+
+
+@pytest.fixture(autouse=True, params=[0, 1], ids=["scan", "readylist"])
+def sweep_mode(request):
+    """Every op-log runs twice: sweeps that scan the queue words, and sweeps that drain the ready list."""
+    SWEEP_MODE[0] = request.param
+    yield request.param
 
 
 def make_pair(oracle_lib, ids, stride, max_count=999, capacity=None, arena=256 << 20, max_batch=1 << 16, delay=2000,
@@ -24,6 +32,7 @@ def make_pair(oracle_lib, ids, stride, max_count=999, capacity=None, arena=256 <
                payload_stride=stride, max_batch=max_batch, check_publish_delay_ms=delay, host_cap_conts=1 << 16,
                host_cap_positions=1 << 20, max_message_bytes=max_message)
     e.set_hot_path(hot_mode)     # -1 automatic, 0 serial walk, 1 parallel kernels for long chains
+    e.set_sweep_path(SWEEP_MODE[0])
     # the oracle keeps whole messages: its row width is the longest message the engine accepts
     o = oracle_lib.Oracle(ids, max_count=max_count, payload_stride=max(stride, max_message), check_publish_delay_ms=delay)
     return e, o, ParityDriver(e, o, ids)
