@@ -569,6 +569,10 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
         LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_kernel<CHAIN_REG><<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, w, (uint32_t)n, now_ms, d_status)));
     // Long chains (hot barriers): the previous batch's longest chain, read back without waiting, picks
     // between the serial kernel and the parallel cx_* kernels.  Both give the same results.
+    // One wave per long chain; the grid follows the previous batch's number of them (an empty pass of 4096
+    // blocks costs 6 us, one of 256 blocks 2 us; a batch that suddenly has many more loops over them once).
+    uint32_t cx_grid = 2 * hint[0];
+    cx_grid = cx_grid < 256 ? 256 : cx_grid > 4096 ? 4096 : cx_grid;
     if (w.cx_on) {
         HIP_TRY(e, hipMemsetAsync(w.cx_keys, 0, CX_HASH * 4, e->stream));
         if (e->profiling) (void)hipEventRecord(e->ev_start[DJ_PROF_JOIN_COMPLEX], e->stream);
@@ -577,10 +581,10 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
         if (sb > 4096) sb = 4096;
         cx_scan_kernel<<<sb, 256, 0, e->stream>>>(w, n, now_ms);
         cx_finalize_kernel<<<1024, 64, 0, e->stream>>>(e->t, w, now_ms);
-        join_resolve_complex_kernel<<<4096, 64, 0, e->stream>>>(e->t, w, (uint32_t)n, now_ms, d_status);
+        join_resolve_complex_kernel<<<cx_grid, 64, 0, e->stream>>>(e->t, w, (uint32_t)n, now_ms, d_status);
         if (e->profiling) { (void)hipEventRecord(e->ev_stop[DJ_PROF_JOIN_COMPLEX], e->stream); e->ev_used[DJ_PROF_JOIN_COMPLEX] = 1; }
     } else {
-        LAUNCH(e, DJ_PROF_JOIN_COMPLEX, (join_resolve_complex_kernel<<<4096, 64, 0, e->stream>>>(e->t, w, (uint32_t)n, now_ms, d_status)));
+        LAUNCH(e, DJ_PROF_JOIN_COMPLEX, (join_resolve_complex_kernel<<<cx_grid, 64, 0, e->stream>>>(e->t, w, (uint32_t)n, now_ms, d_status)));
     }
     const uint32_t lanes = e->cfg.payload_stride / 16;
     if (lanes <= 4) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<4>(e, w, n, d_recs, d_payloads, pitch, d_status));

@@ -189,6 +189,12 @@ class EngineStore:
             out.append(k)
         return out
 
+    @staticmethod
+    def _redis_order(conts):
+        """ZRANGEBYSCORE order (redis.clj:286): by score, then by member bytes.  The engine hands a sweep's
+        barriers over in table order; the host, which has the id strings, restores Redis' order."""
+        return sorted(conts, key=lambda k: (k.publish_at, k.barrier_id.encode()))
+
     # redis/all-publish-messages (redis.clj:283-289)
     def pop_due(self, now_ms):
         out = []
@@ -196,7 +202,7 @@ class EngineStore:
             conts, more = self.e.pop_due(now_ms)
             out += self._conts(conts)
             if not more:
-                return out
+                return self._redis_order(out)
 
     # pop + join-metadata + all-joins for every due barrier (core.clj:184-188,175,163)
     def sweep(self, now_ms):
@@ -205,7 +211,7 @@ class EngineStore:
             conts, lens, mws, pay, more = self.e.sweep(now_ms)
             out += self._conts(conts, lens, mws, pay)
             if not more:
-                return out
+                return self._redis_order(out)
 
     # core/complete / attempt-retry-publish for published (ok) or failed continuations
     def ack(self, conts, oks, now_ms):

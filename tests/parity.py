@@ -2,8 +2,9 @@
 every observable result (per-event statuses, popped continuations with their position-
 ordered messages and timeout classification, ack / recover outcomes, final snapshots).
 
-Bit-exact bar: statuses, counters, scores and message bytes must be equal; continuation
-order inside one sweep is unspecified (a set), as is Redis' order once ids are fingerprints.
+Bit-exact bar: statuses, counters, scores and message bytes must be equal.  The engine hands a sweep's
+continuations over in no particular order; the host that holds the id strings sorts them the way Redis
+returns a ZRANGEBYSCORE (score, then member bytes: redis.clj:283-289), and that list must equal the oracle's.
 """
 import numpy as np
 
@@ -90,6 +91,11 @@ class ParityDriver:
             msgs.append(None if ln == capi.DJ_NIL else (bytes(pay[b + p, :ln]), int(mws[b + p])))
         return head, tuple(msgs)
 
+    def redis_order(self, conts):
+        """Engine continuations in the order Redis pops them: by score, then by member (id) bytes."""
+        live = [c for c in conts if not int(c["flags"]) & capi.CONT_VOID]
+        return sorted(live, key=lambda c: (int(c["publish_at"]), self.ids[self.by_fp[(int(c["fp_lo"]), int(c["fp_hi"]))]].encode()))
+
     def sweep(self, now):
         conts, lens, mws, pay, more = self.e.sweep(now)
         assert not more, "engine sweep hit its host caps in a parity test"
@@ -98,6 +104,9 @@ class ParityDriver:
         assert got.keys() == want.keys(), f"popped sets differ: only engine {sorted(got.keys() - want.keys())[:10]} only oracle {sorted(want.keys() - got.keys())[:10]}"
         for k in want:
             assert got[k] == want[k], f"continuation of {self.ids[k]} differs: {self._diff(got[k], want[k])}"
+        order_e = [self.by_fp[(int(c["fp_lo"]), int(c["fp_hi"]))] for c in self.redis_order(conts)]
+        order_o = [int(c["id_idx"]) for c in oc]
+        assert order_e == order_o, "pop order differs from the oracle's (score, member) order"
         return conts, oc
 
     @staticmethod
@@ -125,20 +134,36 @@ class ParityDriver:
         oc = self.o.pop_due(now)
         got, want = self._canon_engine(conts), self._canon_oracle(oc)
         assert got == want, f"pop_due differs: engine {got} oracle {want}"
+        assert [self.by_fp[(int(c["fp_lo"]), int(c["fp_hi"]))] for c in self.redis_order(conts)] == [int(c["id_idx"]) for c in oc]
         return conts, oc
 
     def ack(self, conts, oconts, ok_of, now):
-        """ok_of: barrier index -> bool.  Acks the same set on both sides, each in its own order."""
-        conts = [c for c in conts if not int(c["flags"]) & capi.CONT_VOID]
-        if not conts:
+        """ok_of: barrier index -> bool.  Acks the same continuations on both sides in the same order (the
+        oracle's: the order of the pop).  A barrier may appear more than once (continuations of two pops acked
+        together): the oracle takes them one by one, the engine side splits the list into calls without
+        repeats, as the host layers do (one barrier at most once per dj_ack_batch call)."""
+        by_idx = {}
+        for c in conts:
+            if not int(c["flags"]) & capi.CONT_VOID:
+                by_idx.setdefault(self.by_fp[(int(c["fp_lo"]), int(c["fp_hi"]))], []).append(c)
+        if not len(oconts):
             return {}
-        ek = [self.by_fp[(int(c["fp_lo"]), int(c["fp_hi"]))] for c in conts]
-        got = self.e.ack_batch(np.array(conts, dtype=capi.CONT), np.array([ok_of(k) for k in ek], dtype=np.uint8), now)
         ok_ = [int(c["id_idx"]) for c in oconts]
-        want = self.o.ack_batch(oconts, np.array([ok_of(k) for k in ok_], dtype=np.uint8), now)
-        g, w = dict(zip(ek, got.tolist())), dict(zip(ok_, want.tolist()))
-        assert g == w, f"ack outcomes differ: {[(self.ids[k], g[k], w.get(k)) for k in g if g[k] != w.get(k)][:10]}"
-        return g
+        ordered = [by_idx[k].pop(0) for k in ok_]          # the engine's records, in the oracle's order
+        oks = np.array([ok_of(k) for k in ok_], dtype=np.uint8)
+        want = self.o.ack_batch(oconts, oks, now)
+        got = np.zeros(len(ordered), dtype=np.int32)
+        pending = list(range(len(ordered)))
+        while pending:
+            seen, batch, rest = set(), [], []
+            for i in pending:
+                (rest if ok_[i] in seen else batch).append(i)
+                seen.add(ok_[i])
+            got[batch] = self.e.ack_batch(np.array([ordered[i] for i in batch], dtype=capi.CONT), oks[batch], now)
+            pending = rest
+        bad = np.nonzero(got != want)[0]
+        assert len(bad) == 0, f"ack outcomes differ: {[(self.ids[ok_[i]], int(got[i]), int(want[i])) for i in bad[:10]]}"
+        return dict(zip(ok_, got.tolist()))
 
     def recover(self, now):
         conts, st, more = self.e.recover(now)

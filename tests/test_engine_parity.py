@@ -3,9 +3,10 @@
 Each op-log mixes forks (re-forks included), joins with duplicates inside one batch (last
 writer wins, redis.clj:135), joins with max-wait, unknown ids and out-of-range positions,
 sweeps at a moving virtual clock, acks with failures (retry counters, exhaustion), joins
-that land between a sweep and its ack (dirty complete, redis.clj:177-188) and recover
-passes.  Not generated, because the engine documents a different outcome there: a failed
-publish whose metadata snapshot carries another :count than the live barrier.
+that land between a sweep and its ack (dirty complete, redis.clj:177-188), recover passes, and
+acks that name a barrier twice (continuations of two pops acked together).  Not generated, because the
+engine documents a different outcome there: a failed publish whose metadata snapshot carries another
+:count than the live barrier.
 """
 import numpy as np
 import pytest
@@ -82,6 +83,11 @@ def run_oplog(d, rng, n_barriers, counts, stride, rounds, batch, hot=None, var_l
                 inflight.append(d.sweep(now))
             if inflight and rng.random() < 0.6:
                 ec, oc = inflight.pop(0)
+                if inflight and rng.random() < 0.4:
+                    # the continuations of two pops acked in one go: a barrier that was popped, re-queued by a
+                    # recover pass or a failed publish and popped again is then in the list twice
+                    ec2, oc2 = inflight.pop(0)
+                    ec, oc = np.concatenate([ec, ec2]), np.concatenate([oc, oc2])
                 now += int(rng.integers(0, 50))
                 d.ack(ec, oc, lambda k: (k * 7 + r) % 5 != 0, now)
         if rng.random() < 0.5:
