@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--zipf-frac", type=float, default=0.0,
                     help="experiment: this fraction of the joins goes to the first 1000 barriers with Zipf(1.2) weights "
                          "(many hot barriers at once; they never complete)")
+    ap.add_argument("--recv-cap", type=int, default=0,
+                    help="experiment: rows a rank's receive buffers hold (default: 2 x batch); smaller values make the exchange "
+                         "take several rounds")
     ap.add_argument("--route", action="store_true",
                     help="run the multi-GPU routing path (partition + all-to-all) even with one rank")
     return ap.parse_args()
@@ -239,7 +242,7 @@ def main():
     router = None
     if routed:
         from distributed_join_amd.router import Router
-        router = Router(eng, dist.group.WORLD, max_send=batch, max_recv=max(recv_cap, nb * 2), pitch=pitch, depth=4)
+        router = Router(eng, dist.group.WORLD, max_send=batch, max_recv=a.recv_cap or max(recv_cap, nb * 2), pitch=pitch, depth=4)
 
     dbg("engine and router ready")
     now = [1_700_000_000_000]
@@ -265,6 +268,9 @@ def main():
                 h = pending_fork.pop(0) if pending_fork else router.start(fork_recs, None, nb)
                 r_recs, _, n_in = router.finish(h)
                 eng.fork_batch_dev(n_in, r_recs, d_status)
+                while router.more(h):           # a rank that owns more than its buffer holds takes the rest in rounds
+                    r_recs, _, n_in = router.next_round(h)
+                    eng.fork_batch_dev(n_in, r_recs, d_status)
                 router.release(h)
         lo = s * batch
         if router is None:
@@ -273,6 +279,9 @@ def main():
             h = pending.pop(0) if pending else start_route(k)
             r_recs, r_pay, n_in = router.finish(h)
             eng.join_batch_dev(n_in, r_recs, r_pay, pitch, now[0], d_status)
+            while router.more(h):               # a hot key's owner takes its rows in several rounds (all ranks take part)
+                r_recs, r_pay, n_in = router.next_round(h)
+                eng.join_batch_dev(n_in, r_recs, r_pay, pitch, now[0], d_status)
             router.release(h)
         d_res = d_res_all[res_i[0] % res_cap]
         res_i[0] += 1
@@ -286,6 +295,9 @@ def main():
             for ahead in range(1, prefetch + 1):
                 if len(pending) < ahead:
                     pending.append(start_route(k + len(pending) + 1))
+            # the batch after this one was started a step ago: its bucket sizes are in, its rows can cross now
+            if pending:
+                router.advance(pending[0])
             if prefetch and s == steps_per_job - 1 and not pending_fork:
                 pending_fork.append(router.start(fork_recs, None, nb))
         if a.hot_frac > 0 or a.zipf_frac > 0:

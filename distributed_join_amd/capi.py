@@ -59,7 +59,8 @@ SYMBOLS = ["dj_create", "dj_destroy", "dj_last_error", "dj_sync", "dj_stream", "
            "dj_queue_scores", "dj_get_stats", "dj_owner_of", "dj_partition_joins", "dj_profile_enable",
            "dj_profile_read", "dj_compact", "dj_set_hot_path", "dj_checkpoint_save", "dj_checkpoint_load",
            "dj_get_config", "dj_fetch_long", "dj_join_batch_static",
-           "dj_set_sweep_path"]
+           "dj_set_sweep_path", "dj_route_plan", "dj_route_unique_id", "dj_router_create", "dj_router_destroy",
+           "dj_router_last_error", "dj_route_start", "dj_route_next", "dj_route_release"]
 # include/dj_batcher.h
 BATCHER_SYMBOLS = ["dj_batcher_create", "dj_batcher_destroy", "dj_batcher_set_clock", "dj_batcher_join",
                    "dj_batcher_fork", "dj_batcher_join_wait", "dj_batcher_fork_wait", "dj_batcher_run",
@@ -154,6 +155,24 @@ def load():
     L.dj_get_config.argtypes = [vp, vp]
     L.dj_fetch_long.restype = i32
     L.dj_fetch_long.argtypes = [vp, u32, vp, vp, vp]
+    if not os.environ.get("DJ_ENGINE_LIB") or hasattr(L, "dj_route_plan"):
+        L.dj_route_plan.restype = u32
+        L.dj_route_plan.argtypes = [u32, u32, vp, u64, u32, vp, vp, vp]
+        L.dj_route_unique_id.restype = i32
+        L.dj_route_unique_id.argtypes = [vp]
+        L.dj_router_create.restype = i32
+        L.dj_router_create.argtypes = [vp, u32, u32, vp, u32, u32, u64, u32, ctypes.POINTER(vp)]
+        L.dj_router_destroy.restype = None
+        L.dj_router_destroy.argtypes = [vp]
+        L.dj_router_last_error.restype = ctypes.c_char_p
+        L.dj_router_last_error.argtypes = [vp]
+        L.dj_route_start.restype = i32
+        L.dj_route_start.argtypes = [vp, u32, vp, vp, ctypes.POINTER(ctypes.c_int)]
+        L.dj_route_next.restype = i32
+        L.dj_route_next.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(u32),
+                                    ctypes.POINTER(ctypes.c_int)]
+        L.dj_route_release.restype = i32
+        L.dj_route_release.argtypes = [vp, ctypes.c_int]
     L.dj_batcher_create.restype = i32
     L.dj_batcher_create.argtypes = [vp, ctypes.POINTER(BatcherConfig), ctypes.POINTER(vp)]
     L.dj_batcher_destroy.restype = None
@@ -202,6 +221,18 @@ def fingerprint_many(ids):
     load().dj_fingerprint_batch(blob.ctypes.data_as(ctypes.c_void_p), offs.ctypes.data_as(ctypes.c_void_p),
                                 len(bs), out.ctypes.data_as(ctypes.c_void_p))
     return out
+
+
+def route_plan(matrix, rank, max_recv, rnd):
+    """dj_route_plan: matrix (world x world, [s][r] = records s holds for r) -> (rounds, send_off, send_cnt,
+    recv_cnt) of `rank` in round `rnd`."""
+    m = np.ascontiguousarray(matrix, dtype=np.uint32)
+    w = m.shape[0]
+    so, sc, rc = (np.zeros(w, dtype=np.uint32) for _ in range(3))
+    p = ctypes.c_void_p
+    rounds = load().dj_route_plan(w, int(rank), m.ctypes.data_as(p), int(max_recv), int(rnd), so.ctypes.data_as(p),
+                                  sc.ctypes.data_as(p), rc.ctypes.data_as(p))
+    return int(rounds), so.tolist(), sc.tolist(), rc.tolist()
 
 
 def owner_of(fp_lo, fp_hi, n_ranks):

@@ -1,0 +1,329 @@
+// dj_router.cpp — multi-GPU routing behind the C ABI (include/dj_engine.h, "routing").
+//
+// Barriers shard by fingerprint over the GPUs of one node (dj_owner_of); a batch of join or fork
+// records reaches its owners with ONE exchange step: stable partition by owner (dj_partition_joins)
+// -> all-gather of the bucket sizes -> grouped send/recv of the buckets over RCCL (xGMI).  The
+// reference has no counterpart: its replicas share one Redis (reference src/distributed_join/redis.clj:13-15).
+//
+// Safety under skew: every rank sees the whole matrix of bucket sizes, so every rank computes the
+// same plan (dj_route_plan): a receiver's incoming rows, in source-rank order, are cut into pieces
+// of at most max_recv rows and exchanged piece by piece.  No rank ever decides alone.
+//
+// RCCL is bound at run time (dlopen), so the engine library loads on hosts without it; only
+// dj_route_unique_id / dj_router_create need it.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "dj_engine.h"
+
+// ---- the plan ------------------------------------------------------------------------------
+extern "C" uint32_t dj_route_plan(uint32_t world, uint32_t rank, const uint32_t* matrix, uint64_t max_recv,
+                                  uint32_t round, uint32_t* send_off, uint32_t* send_cnt, uint32_t* recv_cnt) {
+    if (world == 0 || rank >= world || !matrix || max_recv == 0) return 0;
+    uint32_t rounds = 1;
+    for (uint32_t r = 0; r < world; ++r) {
+        uint64_t total = 0;
+        for (uint32_t s = 0; s < world; ++s) total += matrix[(size_t)s * world + r];
+        const uint64_t k = (total + max_recv - 1) / max_recv;
+        if (k > rounds) rounds = (uint32_t)k;
+    }
+    const uint64_t lo = (uint64_t)round * max_recv, hi = lo + max_recv;      // this round's window of every receiver's stream
+    auto piece = [&](uint32_t s, uint32_t r, uint32_t* off, uint32_t* cnt) {
+        uint64_t before = 0;                                                 // rows of lower source ranks in r's stream
+        for (uint32_t q = 0; q < s; ++q) before += matrix[(size_t)q * world + r];
+        const uint64_t end = before + matrix[(size_t)s * world + r];
+        const uint64_t a = before > lo ? before : lo, b = end < hi ? end : hi;
+        *off = a < b ? (uint32_t)(a - before) : 0;
+        *cnt = a < b ? (uint32_t)(b - a) : 0;
+    };
+    for (uint32_t p = 0; p < world; ++p) {
+        uint32_t off, cnt;
+        if (send_off || send_cnt) {
+            piece(rank, p, &off, &cnt);
+            if (send_off) send_off[p] = off;
+            if (send_cnt) send_cnt[p] = cnt;
+        }
+        if (recv_cnt) {
+            piece(p, rank, &off, &cnt);
+            recv_cnt[p] = cnt;
+        }
+    }
+    return rounds;
+}
+
+// ---- RCCL, bound at run time ------------------------------------------------------------------
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+thread_local std::string g_router_err;
+
+bool rccl_load(std::string* why) {
+    std::lock_guard<std::mutex> g(g_rccl_mu);
+    if (g_rccl.lib) return true;
+    void* lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) { *why = std::string("librccl not found: ") + dlerror(); return false; }
+    Rccl r;
+    r.lib = lib;
+#define BIND(field, name) \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(lib, name)); \
+    if (!r.field) { *why = std::string("librccl lacks ") + name; return false; }
+    BIND(GetUniqueId, "ncclGetUniqueId")
+    BIND(CommInitRank, "ncclCommInitRank")
+    BIND(CommDestroy, "ncclCommDestroy")
+    BIND(GroupStart, "ncclGroupStart")
+    BIND(GroupEnd, "ncclGroupEnd")
+    BIND(Send, "ncclSend")
+    BIND(Recv, "ncclRecv")
+    BIND(AllGather, "ncclAllGather")
+    BIND(GetErrorString, "ncclGetErrorString")
+#undef BIND
+    g_rccl = r;
+    return true;
+}
+
+constexpr int MAX_RANKS = 64;     // dj_partition_joins' limit
+constexpr int MAX_DEPTH = 8;
+
+struct Set {
+    dj_join_rec* recs_sorted = nullptr;
+    uint8_t* pay_sorted = nullptr;
+    uint32_t* origin = nullptr;
+    uint32_t* counts = nullptr;       // [world] this rank's bucket sizes (device)
+    uint32_t* matrix_d = nullptr;     // [world * world] everybody's
+    uint32_t* matrix_h = nullptr;     // pinned copy
+    dj_join_rec* recv_recs = nullptr;
+    uint8_t* recv_pay = nullptr;
+    hipEvent_t counts_ev = nullptr, ready = nullptr, freed = nullptr;
+    bool free_pending = false, has_pay = false, active = false, planned = false;
+    uint32_t n = 0, rounds = 0, round = 0;
+    uint32_t bucket_off[MAX_RANKS];   // where each destination's bucket starts in recs_sorted
+};
+}  // namespace
+
+struct dj_router {
+    dj_engine* e = nullptr;
+    dj_config cfg;
+    int world = 0, rank = 0, depth = 0, turn = 0;
+    uint32_t max_send = 0, max_recv = 0;
+    uint64_t pitch = 0;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr, engine_stream = nullptr;
+    Set sets[MAX_DEPTH];
+    std::string err;
+    std::mutex mu;
+};
+
+static int rfail(dj_router* r, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (r) r->err = buf; else g_router_err = buf;
+    return code;
+}
+
+#define R_HIP(r, call)                                                                                  \
+    do {                                                                                                \
+        hipError_t _e = (call);                                                                         \
+        if (_e != hipSuccess) return rfail(r, DJ_E_HIP, "%s failed: %s", #call, hipGetErrorString(_e)); \
+    } while (0)
+#define R_NCCL(r, call)                                                                                      \
+    do {                                                                                                     \
+        ncclResult_t _e = (call);                                                                            \
+        if (_e != ncclSuccess) return rfail(r, DJ_E_HIP, "%s failed: %s", #call, g_rccl.GetErrorString(_e)); \
+    } while (0)
+
+extern "C" const char* dj_router_last_error(const dj_router* r) { return r ? r->err.c_str() : g_router_err.c_str(); }
+
+extern "C" int dj_route_unique_id(uint8_t* id128) {
+    if (!id128) return rfail(nullptr, DJ_E_INVALID, "null argument");
+    std::string why;
+    if (!rccl_load(&why)) return rfail(nullptr, DJ_E_INVALID, "%s", why.c_str());
+    static_assert(sizeof(ncclUniqueId) == 128, "the id travels as 128 bytes");
+    ncclUniqueId id;
+    R_NCCL(nullptr, g_rccl.GetUniqueId(&id));
+    memcpy(id128, &id, 128);
+    return DJ_OK;
+}
+
+extern "C" void dj_router_destroy(dj_router* r) {
+    if (!r) return;
+    (void)hipSetDevice(r->cfg.device);
+    if (r->stream) (void)hipStreamSynchronize(r->stream);
+    for (int k = 0; k < r->depth; ++k) {
+        Set& s = r->sets[k];
+        (void)hipFree(s.recs_sorted); (void)hipFree(s.pay_sorted); (void)hipFree(s.origin); (void)hipFree(s.counts);
+        (void)hipFree(s.matrix_d); (void)hipFree(s.recv_recs); (void)hipFree(s.recv_pay);
+        if (s.matrix_h) (void)hipHostFree(s.matrix_h);
+        if (s.counts_ev) (void)hipEventDestroy(s.counts_ev);
+        if (s.ready) (void)hipEventDestroy(s.ready);
+        if (s.freed) (void)hipEventDestroy(s.freed);
+    }
+    if (r->comm) (void)g_rccl.CommDestroy(r->comm);
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    delete r;
+}
+
+extern "C" int dj_router_create(dj_engine* e, uint32_t n_ranks, uint32_t rank, const uint8_t* id128, uint32_t max_send,
+                                uint32_t max_recv, uint64_t pitch, uint32_t depth, dj_router** out) {
+    if (!e || !id128 || !out) return rfail(nullptr, DJ_E_INVALID, "null argument");
+    if (n_ranks < 1 || n_ranks > MAX_RANKS || rank >= n_ranks) return rfail(nullptr, DJ_E_INVALID, "n_ranks must be 1..%d, rank below it", MAX_RANKS);
+    if (depth < 1 || depth > MAX_DEPTH) return rfail(nullptr, DJ_E_INVALID, "depth must be 1..%d", MAX_DEPTH);
+    if (max_send < 1 || max_recv < 1 || pitch == 0 || pitch % 16) return rfail(nullptr, DJ_E_INVALID, "max_send, max_recv >= 1, pitch a positive multiple of 16");
+    std::string why;
+    if (!rccl_load(&why)) return rfail(nullptr, DJ_E_INVALID, "%s", why.c_str());
+    dj_router* r = new (std::nothrow) dj_router();
+    if (!r) return rfail(nullptr, DJ_E_NOMEM, "out of host memory");
+    r->e = e;
+    r->world = (int)n_ranks; r->rank = (int)rank; r->depth = (int)depth;
+    r->max_send = max_send; r->max_recv = max_recv; r->pitch = pitch;
+    int rc = dj_get_config(e, &r->cfg);
+    if (rc == DJ_OK && max_send > r->cfg.max_batch) rc = rfail(nullptr, DJ_E_TOO_LARGE, "max_send exceeds the engine's max_batch");
+    auto body = [&]() -> int {
+        R_HIP(nullptr, hipSetDevice(r->cfg.device));
+        R_HIP(nullptr, hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+        r->engine_stream = (hipStream_t)dj_stream(e);
+        for (int k = 0; k < r->depth; ++k) {
+            Set& s = r->sets[k];
+            R_HIP(nullptr, hipMalloc((void**)&s.recs_sorted, (size_t)max_send * 32));
+            R_HIP(nullptr, hipMalloc((void**)&s.pay_sorted, (size_t)max_send * pitch));
+            R_HIP(nullptr, hipMalloc((void**)&s.origin, (size_t)max_send * 4));
+            R_HIP(nullptr, hipMalloc((void**)&s.counts, MAX_RANKS * 4));
+            R_HIP(nullptr, hipMalloc((void**)&s.matrix_d, (size_t)MAX_RANKS * MAX_RANKS * 4));
+            R_HIP(nullptr, hipHostMalloc((void**)&s.matrix_h, (size_t)MAX_RANKS * MAX_RANKS * 4, hipHostMallocDefault));
+            R_HIP(nullptr, hipMalloc((void**)&s.recv_recs, (size_t)max_recv * 32));
+            R_HIP(nullptr, hipMalloc((void**)&s.recv_pay, (size_t)max_recv * pitch));
+            R_HIP(nullptr, hipEventCreateWithFlags(&s.counts_ev, hipEventDisableTiming));
+            R_HIP(nullptr, hipEventCreateWithFlags(&s.ready, hipEventDisableTiming));
+            R_HIP(nullptr, hipEventCreateWithFlags(&s.freed, hipEventDisableTiming));
+        }
+        ncclUniqueId id;
+        memcpy(&id, id128, 128);
+        R_NCCL(nullptr, g_rccl.CommInitRank(&r->comm, r->world, id, r->rank));
+        return DJ_OK;
+    };
+    if (rc == DJ_OK) rc = body();
+    if (rc != DJ_OK) {
+        dj_router_destroy(r);
+        return rc;
+    }
+    *out = r;
+    return DJ_OK;
+}
+
+extern "C" int dj_route_start(dj_router* r, uint32_t n, const dj_join_rec* d_recs, const uint8_t* d_payloads, int* handle) {
+    if (!r || !handle) return DJ_E_INVALID;
+    std::lock_guard<std::mutex> g(r->mu);
+    if (n > r->max_send) return rfail(r, DJ_E_TOO_LARGE, "route: n=%u exceeds max_send=%u", n, r->max_send);
+    if (n && !d_recs) return rfail(r, DJ_E_INVALID, "route: null records");
+    Set& s = r->sets[r->turn];
+    if (s.active) return rfail(r, DJ_E_INVALID, "route: all %d buffer sets are in use (dj_route_release the oldest)", r->depth);
+    R_HIP(r, hipSetDevice(r->cfg.device));
+    if (s.free_pending) {                 // the engine may still be reading this set's receive buffers
+        R_HIP(r, hipStreamWaitEvent(r->stream, s.freed, 0));
+        s.free_pending = false;
+    }
+    s.has_pay = d_payloads != nullptr;
+    s.n = n;
+    s.planned = false;
+    s.round = s.rounds = 0;
+    int rc = dj_partition_joins(r->e, n, (uint32_t)r->world, d_recs, d_payloads, r->pitch, s.recs_sorted,
+                                s.has_pay ? s.pay_sorted : nullptr, s.origin, s.counts, r->stream);
+    if (rc != DJ_OK) return rfail(r, rc, "route: partition failed: %s", dj_last_error(r->e));
+    // everybody's bucket sizes to everybody (world * world words), then to this host without waiting
+    R_NCCL(r, g_rccl.AllGather(s.counts, s.matrix_d, (size_t)r->world, ncclUint32, r->comm, r->stream));
+    R_HIP(r, hipMemcpyAsync(s.matrix_h, s.matrix_d, (size_t)r->world * r->world * 4, hipMemcpyDeviceToHost, r->stream));
+    R_HIP(r, hipEventRecord(s.counts_ev, r->stream));
+    s.active = true;
+    *handle = r->turn;
+    r->turn = (r->turn + 1) % r->depth;
+    return DJ_OK;
+}
+
+extern "C" int dj_route_next(dj_router* r, int handle, const dj_join_rec** d_recs_out, const uint8_t** d_payloads_out,
+                             uint32_t* n_out, int* more) {
+    if (!r || handle < 0 || handle >= r->depth || !d_recs_out || !n_out || !more) return DJ_E_INVALID;
+    std::lock_guard<std::mutex> g(r->mu);
+    Set& s = r->sets[handle];
+    if (!s.active) return rfail(r, DJ_E_INVALID, "route: handle %d is not in flight", handle);
+    R_HIP(r, hipSetDevice(r->cfg.device));
+    const uint32_t w = (uint32_t)r->world;
+    if (!s.planned) {
+        R_HIP(r, hipEventSynchronize(s.counts_ev));      // already there when the start was issued a batch ahead
+        uint32_t off = 0;
+        for (uint32_t p = 0; p < w; ++p) { s.bucket_off[p] = off; off += s.matrix_h[(size_t)r->rank * w + p]; }
+        s.rounds = dj_route_plan(w, (uint32_t)r->rank, s.matrix_h, r->max_recv, 0, nullptr, nullptr, nullptr);
+        s.planned = true;
+    } else {
+        if (s.round >= s.rounds) return rfail(r, DJ_E_INVALID, "route: handle %d has no piece left", handle);
+        // the receive buffers are reused: wait for what the engine's stream holds so far (the caller has
+        // queued the kernels that read the previous piece)
+        R_HIP(r, hipEventRecord(s.freed, r->engine_stream));
+        R_HIP(r, hipStreamWaitEvent(r->stream, s.freed, 0));
+    }
+    uint32_t send_off[MAX_RANKS], send_cnt[MAX_RANKS], recv_cnt[MAX_RANKS];
+    dj_route_plan(w, (uint32_t)r->rank, s.matrix_h, r->max_recv, s.round, send_off, send_cnt, recv_cnt);
+    uint32_t n_in = 0, at[MAX_RANKS];
+    for (uint32_t p = 0; p < w; ++p) { at[p] = n_in; n_in += recv_cnt[p]; }
+    for (int pass = 0; pass < (s.has_pay ? 2 : 1); ++pass) {
+        const size_t row = pass == 0 ? 32 : (size_t)r->pitch;
+        const uint8_t* src = pass == 0 ? reinterpret_cast<const uint8_t*>(s.recs_sorted) : s.pay_sorted;
+        uint8_t* dst = pass == 0 ? reinterpret_cast<uint8_t*>(s.recv_recs) : s.recv_pay;
+        R_NCCL(r, g_rccl.GroupStart());
+        for (uint32_t p = 0; p < w; ++p) {
+            const uint8_t* from = src + (size_t)(s.bucket_off[p] + send_off[p]) * row;
+            uint8_t* to = dst + (size_t)at[p] * row;
+            if ((int)p == r->rank) {
+                if (send_cnt[p]) R_HIP(r, hipMemcpyAsync(to, from, (size_t)send_cnt[p] * row, hipMemcpyDeviceToDevice, r->stream));
+                continue;
+            }
+            if (send_cnt[p]) R_NCCL(r, g_rccl.Send(from, (size_t)send_cnt[p] * row, ncclUint8, (int)p, r->comm, r->stream));
+            if (recv_cnt[p]) R_NCCL(r, g_rccl.Recv(to, (size_t)recv_cnt[p] * row, ncclUint8, (int)p, r->comm, r->stream));
+        }
+        R_NCCL(r, g_rccl.GroupEnd());
+    }
+    R_HIP(r, hipEventRecord(s.ready, r->stream));
+    R_HIP(r, hipStreamWaitEvent(r->engine_stream, s.ready, 0));      // the engine's stream waits, the host does not
+    ++s.round;
+    *d_recs_out = s.recv_recs;
+    if (d_payloads_out) *d_payloads_out = s.has_pay ? s.recv_pay : nullptr;
+    *n_out = n_in;
+    *more = s.round < s.rounds ? 1 : 0;
+    return DJ_OK;
+}
+
+extern "C" int dj_route_release(dj_router* r, int handle) {
+    if (!r || handle < 0 || handle >= r->depth) return DJ_E_INVALID;
+    std::lock_guard<std::mutex> g(r->mu);
+    Set& s = r->sets[handle];
+    if (!s.active) return rfail(r, DJ_E_INVALID, "route: handle %d is not in flight", handle);
+    if (s.planned && s.round < s.rounds) return rfail(r, DJ_E_INVALID, "route: handle %d still has pieces to exchange (a collective: every rank must take them)", handle);
+    R_HIP(r, hipSetDevice(r->cfg.device));
+    R_HIP(r, hipEventRecord(s.freed, r->engine_stream));
+    s.free_pending = true;
+    s.active = false;
+    return DJ_OK;
+}

@@ -6,23 +6,33 @@ src/distributed_join/redis.clj:13-15); the exchange is the only collective on th
 sweeps, gathers, acks and recovers are GPU-local.
 
 route = partition (HIP kernels, dj_partition_joins: stable, so every owner sees the events of
-one source in array order) + counts exchange + two all_to_all_single calls (records,
+one source in array order) + all-gather of the bucket sizes + all_to_all_single calls (records,
 messages).  The receiver's order is: source rank 0's events, then rank 1's, ...
 
-The router works on its OWN stream with several buffer sets (three by default), so the routing of
-batches k+1 and k+2 (its kernels, its collectives and the host's wait for the bucket sizes) runs
-while the engine's stream applies batch k; with two batches in flight neither stream waits for
-the host:
-    h = router.start(recs, payloads, n)     # partition + exchange, asynchronous
-    ...                                      # the engine applies the previous batch
-    recs_in, pay_in, n_in = router.finish(h) # the engine's stream waits for the data (no host wait)
+Skew: every rank holds the whole matrix of bucket sizes, so every rank computes the same plan
+(dj_route_plan, the function the C router of include/dj_engine.h uses too): a receiver whose incoming
+rows exceed its buffer (a hot key owns half of everybody's batch) takes them in several rounds, each a
+collective that all ranks enter.  No rank raises while its peers sit in a collective.
+
+The router works on its OWN stream with several buffer sets, so the routing of batches k+1 and
+k+2 runs while the engine's stream applies batch k, and start() never waits for the device: the
+host needs the bucket sizes only when the rows are exchanged (advance() / finish()), one batch later.
+    h = router.start(recs, payloads, n)      # partition + bucket sizes, asynchronous
+    ...                                       # the engine applies the previous batch
+    router.advance(h)                         # optional: exchange the first piece now (sizes are in by now)
+    recs_in, pay_in, n_in = router.finish(h)  # the engine's stream waits for the data (no host wait)
     engine.join_batch_dev(n_in, recs_in, pay_in, ...)
-    router.release(h)                        # after the batch's kernels are queued: buffers may be reused
+    while router.more(h):                     # only under skew beyond the receive buffer
+        recs_in, pay_in, n_in = router.next_round(h)
+        engine.join_batch_dev(n_in, recs_in, pay_in, ...)
+    router.release(h)                         # after the batch's kernels are queued: buffers may be reused
 """
 import os
 import sys
 
 import numpy as np
+
+from . import capi
 
 _DEBUG = bool(os.environ.get("DJ_BENCH_DEBUG"))
 
@@ -38,51 +48,76 @@ def owner_of_np(fp_hi, n_ranks):
     return ((np.asarray(fp_hi, dtype=np.uint64) >> np.uint64(17)) % np.uint64(n_ranks)).astype(np.int64)
 
 
-def exchange(dist, group, recs_sorted, pay_sorted, send_counts, recv_recs, recv_pay):
-    """all-to-all-v of records (rows of recs_sorted) and messages (rows of pay_sorted, optional).
-    send_counts: python list, rows for each destination rank.  Returns (n_received, recv_counts).
-    Works on any torch.distributed backend (RCCL on GPUs, gloo on CPU tensors)."""
+def gather_matrix(dist, group, send_counts, device=None):
+    """All ranks' bucket sizes: -> numpy (world, world), [s][r] = rows rank s holds for rank r.  Blocking."""
     import torch
     world = dist.get_world_size(group)
-    sc = torch.tensor(send_counts, dtype=torch.int64, device=recs_sorted.device)
-    rc = torch.empty(world, dtype=torch.int64, device=recs_sorted.device)
-    dist.all_to_all_single(rc, sc, group=group)
-    recv_counts = [int(x) for x in rc.cpu().tolist()]
-    return exchange_rows(dist, group, recs_sorted, pay_sorted, send_counts, recv_counts, recv_recs, recv_pay)
+    mine = torch.tensor(send_counts, dtype=torch.int64, device=device)
+    parts = [torch.empty(world, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    return torch.stack(parts).cpu().numpy().astype(np.uint32)
 
 
-def exchange_rows(dist, group, recs_sorted, pay_sorted, send_counts, recv_counts, recv_recs, recv_pay):
-    """The data part of exchange(): both sides' bucket sizes are known."""
-    n_in, n_out = sum(recv_counts), sum(send_counts)
-    if n_in > recv_recs.shape[0]:
-        raise RuntimeError(f"router: {n_in} incoming records exceed the receive buffer ({recv_recs.shape[0]})")
-    _dbg("records a2a", n_out, "->", n_in)
-    dist.all_to_all_single(recv_recs[:n_in], recs_sorted[:n_out], output_split_sizes=recv_counts,
-                           input_split_sizes=list(send_counts), group=group)
-    _dbg("records done")
+def exchange_round(dist, group, rank, matrix, max_recv, rnd, recs_sorted, pay_sorted, recv_recs, recv_pay):
+    """One round of the planned exchange on any torch.distributed backend (RCCL on GPUs, gloo on CPU
+    tensors).  -> (rows received, rounds in all)."""
+    import torch
+    rounds, send_off, send_cnt, recv_cnt = capi.route_plan(matrix, rank, max_recv, rnd)
+    bucket = [int(x) for x in matrix[rank]]
+    starts = np.concatenate([[0], np.cumsum(bucket)[:-1]]).tolist()
+    n_in, n_out = sum(recv_cnt), sum(send_cnt)
+    whole = all(o == 0 and c == b for o, c, b in zip(send_off, send_cnt, bucket))
+
+    def rows(t):
+        if whole:
+            return t[:n_out]
+        return torch.cat([t[st + o:st + o + c] for st, o, c in zip(starts, send_off, send_cnt)])
+
+    _dbg("round", rnd, "of", rounds, ":", n_out, "->", n_in)
+    dist.all_to_all_single(recv_recs[:n_in], rows(recs_sorted), output_split_sizes=recv_cnt, input_split_sizes=send_cnt,
+                           group=group)
     if pay_sorted is not None:
-        dist.all_to_all_single(recv_pay[:n_in], pay_sorted[:n_out], output_split_sizes=recv_counts,
-                               input_split_sizes=list(send_counts), group=group)
-    return n_in, recv_counts
+        dist.all_to_all_single(recv_pay[:n_in], rows(pay_sorted), output_split_sizes=recv_cnt, input_split_sizes=send_cnt,
+                               group=group)
+    return n_in, rounds
+
+
+def exchange(dist, group, recs_sorted, pay_sorted, send_counts, recv_recs, recv_pay):
+    """all-to-all-v of records (rows of recs_sorted, grouped by destination rank) and messages (rows of
+    pay_sorted, optional) in as many rounds as the receive buffers need; the pieces are handed to `yield`-free
+    callers as a list: -> [(n_received, recv_recs copy, recv_pay copy or None), ...] in application order."""
+    rank = dist.get_rank(group)
+    matrix = gather_matrix(dist, group, send_counts, device=recs_sorted.device)
+    out, rnd, rounds = [], 0, 1
+    while rnd < rounds:
+        n_in, rounds = exchange_round(dist, group, rank, matrix, recv_recs.shape[0], rnd, recs_sorted, pay_sorted,
+                                      recv_recs, recv_pay)
+        out.append((n_in, recv_recs[:n_in].clone(), recv_pay[:n_in].clone() if pay_sorted is not None else None))
+        rnd += 1
+    return out
 
 
 class _Slot:
     """One buffer set."""
 
-    def __init__(self, torch, dev, max_send, max_recv, pitch):
+    def __init__(self, torch, dev, world, max_send, max_recv, pitch):
         self.recs_sorted = torch.empty((max_send, 4), dtype=torch.int64, device=dev)
         self.pay_sorted = torch.empty((max_send, pitch), dtype=torch.uint8, device=dev)
         self.origin = torch.empty(max_send, dtype=torch.int32, device=dev)
         self.counts = torch.empty(64, dtype=torch.int32, device=dev)
-        self.counts_in = torch.empty(64, dtype=torch.int32, device=dev)
-        self.h_counts = torch.empty(128, dtype=torch.int32).pin_memory()   # [0:64] sent, [64:128] received
+        self.matrix_d = torch.empty(world * world, dtype=torch.int32, device=dev)
+        self.matrix_h = torch.empty(world * world, dtype=torch.int32).pin_memory()
         self.recv_recs = torch.empty((max_recv, 4), dtype=torch.int64, device=dev)
         self.recv_pay = torch.empty((max_recv, pitch), dtype=torch.uint8, device=dev)
+        self.sizes_in = torch.cuda.Event()   # the bucket sizes are in host memory
         self.ready = torch.cuda.Event()      # data has arrived (recorded on the router's stream)
         self.free = torch.cuda.Event()       # the engine has consumed it (recorded on the engine's stream)
         self.free_pending = False
         self.n_in = 0
         self.has_pay = False
+        self.matrix = None                   # numpy (world, world) once the sizes were read
+        self.round = self.rounds = 0
+        self.host = None                     # host-staged form: (records, messages) as CPU tensors
 
 
 class Router:
@@ -92,11 +127,13 @@ class Router:
         self.torch = torch
         self.e, self.group, self.dist = engine, group, dist
         self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
         self.pitch = int(pitch)
+        self.max_recv = int(max_recv)
         dev = engine.device
         self.stream = torch.cuda.Stream(device=dev)
         self.engine_stream = engine.torch_stream()
-        self.slots = [_Slot(torch, dev, max_send, max_recv, self.pitch) for _ in range(max(2, int(depth)))]
+        self.slots = [_Slot(torch, dev, self.world, max_send, max_recv, self.pitch) for _ in range(max(2, int(depth)))]
         self.turn = 0
         # gloo (tests, rehearsals on one GPU) moves device tensors through worker threads without
         # blocking the caller, and several such exchanges in flight can pair up differently on two
@@ -106,7 +143,8 @@ class Router:
     def start(self, d_recs, d_payloads, n):
         """Begin routing n records (rows of the (n, 4) int64 tensor d_recs: dj_join_rec or dj_fork_rec)
         with their messages ((n, pitch) uint8, or None).  The inputs must already be complete on the
-        device.  Returns a handle for finish()."""
+        device.  Queues the partition and the exchange of the bucket sizes; does not wait for them.
+        Returns a handle for advance() / finish()."""
         torch = self.torch
         s = self.slots[self.turn]
         self.turn = (self.turn + 1) % len(self.slots)
@@ -115,45 +153,77 @@ class Router:
                 self.stream.wait_event(s.free)
                 s.free_pending = False
             s.has_pay = d_payloads is not None
+            s.matrix, s.round, s.rounds, s.host = None, 0, 0, None
             self.e.partition_joins_dev(n, self.world, d_recs, d_payloads, self.pitch, s.recs_sorted,
                                        s.pay_sorted if s.has_pay else None, s.origin, s.counts,
                                        stream_ptr=self.stream.cuda_stream)
             if self.host_staged:
-                self._exchange_host_staged(s, n)
                 return s
-            # bucket sizes travel rank to rank on the device; ONE read-back brings both sides' sizes to the host
             w = self.world
-            _dbg("partition queued, exchanging bucket sizes")
-            self.dist.all_to_all_single(s.counts_in[:w], s.counts[:w], group=self.group)
-            s.h_counts[:64].copy_(s.counts, non_blocking=True)
-            s.h_counts[64:].copy_(s.counts_in, non_blocking=True)
-            self.stream.synchronize()                 # waits for the router's stream only
-            hc = s.h_counts.tolist()
-            _dbg("bucket sizes", hc[:w], hc[64:64 + w])
-            s.n_in, _ = exchange_rows(self.dist, self.group, s.recs_sorted, s.pay_sorted if s.has_pay else None,
-                                      hc[:w], hc[64:64 + w], s.recv_recs, s.recv_pay)
-            s.ready.record(self.stream)
-            _dbg("rows exchanged")
+            self.dist.all_gather_into_tensor(s.matrix_d, s.counts[:w], group=self.group)
+            s.matrix_h.copy_(s.matrix_d, non_blocking=True)
+            s.sizes_in.record(self.stream)
         return s
 
-    def _exchange_host_staged(self, s, n):
-        torch, w = self.torch, self.world
-        self.stream.synchronize()
-        counts = [int(x) for x in s.counts[:w].cpu().tolist()]
-        n_out = sum(counts)
-        rs = s.recs_sorted[:n_out].cpu()
-        ps = s.pay_sorted[:n_out].cpu() if s.has_pay else None
-        rr = torch.empty((s.recv_recs.shape[0], 4), dtype=torch.int64)
-        rp = torch.empty((s.recv_pay.shape[0], self.pitch), dtype=torch.uint8) if s.has_pay else None
-        s.n_in, _ = exchange(self.dist, self.group, rs, ps, counts, rr, rp)
-        s.recv_recs[:s.n_in].copy_(rr[:s.n_in], non_blocking=False)
-        if s.has_pay:
-            s.recv_pay[:s.n_in].copy_(rp[:s.n_in], non_blocking=False)
-        s.ready.record(self.stream)
+    def _plan(self, s):
+        if s.matrix is not None:
+            return
+        w = self.world
+        if self.host_staged:
+            self.stream.synchronize()
+            counts = [int(x) for x in s.counts[:w].cpu().tolist()]
+            s.matrix = gather_matrix(self.dist, self.group, counts)
+            n_out = sum(counts)
+            s.host = (s.recs_sorted[:n_out].cpu(), s.pay_sorted[:n_out].cpu() if s.has_pay else None)
+        else:
+            s.sizes_in.synchronize()                  # in long ago when the start was issued a batch ahead
+            s.matrix = s.matrix_h.numpy().astype(np.uint32).reshape(w, w).copy()
+        _dbg("bucket sizes", s.matrix.tolist())
+
+    def _exchange(self, s):
+        torch = self.torch
+        self._plan(s)
+        with torch.cuda.stream(self.stream):
+            if s.round > 0:
+                # the receive buffers are reused: the engine's kernels that read the previous piece are queued
+                s.free.record(self.engine_stream)
+                self.stream.wait_event(s.free)
+            if self.host_staged:
+                rr = torch.empty((self.max_recv, 4), dtype=torch.int64)
+                rp = torch.empty((self.max_recv, self.pitch), dtype=torch.uint8) if s.has_pay else None
+                self.stream.synchronize()
+                s.n_in, s.rounds = exchange_round(self.dist, self.group, self.rank, s.matrix, self.max_recv, s.round,
+                                                  s.host[0], s.host[1], rr, rp)
+                s.recv_recs[:s.n_in].copy_(rr[:s.n_in], non_blocking=False)
+                if s.has_pay:
+                    s.recv_pay[:s.n_in].copy_(rp[:s.n_in], non_blocking=False)
+            else:
+                s.n_in, s.rounds = exchange_round(self.dist, self.group, self.rank, s.matrix, self.max_recv, s.round,
+                                                  s.recs_sorted, s.pay_sorted if s.has_pay else None, s.recv_recs, s.recv_pay)
+            s.ready.record(self.stream)
+        s.round += 1
+
+    def advance(self, s):
+        """Exchange the first piece now (the host waits for the bucket sizes if they are not in yet).  Optional:
+        finish() does it otherwise.  A collective: every rank calls it at the same point of its sequence."""
+        if s.round == 0:
+            self._exchange(s)
 
     def finish(self, s):
-        """-> (records for this rank, messages for this rank or None, n_received).  The engine's stream
-        waits for the exchange; the host does not."""
+        """-> (records for this rank, messages for this rank or None, n_received) of the first piece.  The
+        engine's stream waits for the exchange; the host does not (beyond the bucket sizes)."""
+        self.advance(s)
+        self.engine_stream.wait_event(s.ready)
+        return s.recv_recs, (s.recv_pay if s.has_pay else None), s.n_in
+
+    def more(self, s):
+        """True while pieces are left (the same answer on every rank)."""
+        return s.round < s.rounds
+
+    def next_round(self, s):
+        """The next piece, into the same buffers: call after the engine call that consumes the previous
+        piece has been queued.  A collective."""
+        self._exchange(s)
         self.engine_stream.wait_event(s.ready)
         return s.recv_recs, (s.recv_pay if s.has_pay else None), s.n_in
 
@@ -163,8 +233,8 @@ class Router:
         s.free_pending = True
 
     def route(self, d_recs, d_payloads, n):
-        """start + finish in one call (no overlap).  The caller releases nothing: the next start() on
-        this buffer set waits for the engine's stream as it is now."""
+        """start + finish in one call (no overlap): -> (records, messages, n_received, handle).  The caller
+        queues the engine call that reads them, takes further pieces while more(handle), then release(handle)."""
         self.torch.cuda.current_stream().synchronize()
         s = self.start(d_recs, d_payloads, n)
         out = self.finish(s)

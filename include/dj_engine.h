@@ -339,6 +339,46 @@ int dj_partition_joins(dj_engine* e, uint32_t n, uint32_t n_ranks,
                        dj_join_rec* d_recs_out, uint8_t* d_payloads_out,
                        uint32_t* d_origin, uint32_t* d_counts, void* stream);
 
+/* ---- the exchange itself (no counterpart in the reference, whose replicas share one Redis:
+ * redis.clj:13-15) ------------------------------------------------------------------------------
+ *
+ * The plan of one batch's exchange, a pure function every rank evaluates on the same matrix
+ * (matrix[s * n_ranks + r] = records rank s holds for rank r, gathered from all ranks): a receiver's
+ * incoming records, taken in source-rank order, are cut into pieces of at most max_recv rows, one piece per
+ * round.  Returns the number of rounds (the same on every rank, at least 1) and, for round `round`, what rank
+ * `rank` sends (send_cnt[r] records of its bucket for r, starting send_off[r] records into that bucket) and
+ * receives (recv_cnt[s] records from s); any of the three arrays may be NULL.  A bucket that is larger than a
+ * receiver's buffer (hot keys) thus costs more rounds, never an error on one rank while the others wait in a
+ * collective.  Applying the pieces one after the other is the same as applying the whole stream: a batch is
+ * defined as its records taken one by one. */
+uint32_t dj_route_plan(uint32_t n_ranks, uint32_t rank, const uint32_t* matrix, uint64_t max_recv, uint32_t round,
+                       uint32_t* send_off, uint32_t* send_cnt, uint32_t* recv_cnt);
+
+/* A router owns a stream of its own, `depth` sets of send/receive buffers and an RCCL communicator over the
+ * n_ranks engines of one node (librccl is bound at run time; only these calls need it).  Rank 0 makes an id
+ * with dj_route_unique_id and hands the 128 bytes to every rank by whatever channel the host has; every rank
+ * then calls dj_router_create (a collective).  One batch:
+ *   dj_route_start   partition + all-gather of the bucket sizes, queued on the router's stream; the host
+ *                    does not wait.  Start the next batches while the engine applies this one.
+ *   dj_route_next    exchanges the next piece (grouped ncclSend/ncclRecv of records, then messages) and makes
+ *                    the ENGINE's stream wait for its arrival; the host waits only for the bucket sizes, which
+ *                    are in when the start was issued a batch ahead.  Returns device pointers to this rank's
+ *                    records / messages, their number and whether more pieces follow (skew beyond max_recv).
+ *                    Queue the engine call that consumes a piece before asking for the next one.
+ *   dj_route_release after the last piece's engine call has been queued: the set may be reused.
+ * Every rank makes the same calls in the same order.  A piece's record order: source rank 0's records in
+ * array order, then rank 1's, ...: a fixed global order, so results do not depend on timing. */
+typedef struct dj_router dj_router;
+int  dj_route_unique_id(uint8_t* id128);
+int  dj_router_create(dj_engine* e, uint32_t n_ranks, uint32_t rank, const uint8_t* id128, uint32_t max_send,
+                      uint32_t max_recv, uint64_t pitch, uint32_t depth, dj_router** out);
+void dj_router_destroy(dj_router* r);
+const char* dj_router_last_error(const dj_router* r);     /* r may be NULL: last create / id error of this thread */
+int  dj_route_start(dj_router* r, uint32_t n, const dj_join_rec* d_recs, const uint8_t* d_payloads, int* handle);
+int  dj_route_next(dj_router* r, int handle, const dj_join_rec** d_recs_out, const uint8_t** d_payloads_out,
+                   uint32_t* n_out, int* more);
+int  dj_route_release(dj_router* r, int handle);
+
 #ifdef __cplusplus
 }
 #endif

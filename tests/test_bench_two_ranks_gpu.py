@@ -12,12 +12,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NB, STEPS = 16384, 16
 
 
-def worker(rank, port, out_dir):
+def worker(rank, port, out_dir, extra=()):
     os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": "2", "MASTER_ADDR": "127.0.0.1",
                        "MASTER_PORT": str(port)})
     sys.path.insert(0, ROOT)
     sys.argv = ["bench.py", "--gpus", "2", "--steps", str(STEPS), "--warmup", "8", "--barriers", str(NB),
-                "--rehearse-on-one-gpu", "--no-cpu-baseline"]
+                "--rehearse-on-one-gpu", "--no-cpu-baseline"] + list(extra)
     sys.stdout = open(os.path.join(out_dir, f"out_{rank}.txt"), "w")
     import bench
     bench.main()
@@ -36,3 +36,19 @@ def test_bench_with_two_ranks_on_one_gpu(tmp_path):
     # every rank generates NB barriers per job; 16 steps = 2 jobs; every barrier fires exactly once
     assert out["continuations_fired"] == 2 * NB * (STEPS // 8)
     assert out["value"] > 0 and out["roofline"]["kernel"] in out["kernels"]
+
+
+def test_bench_with_a_hot_key_and_small_receive_buffers(tmp_path):
+    """Half of every rank's joins on one barrier, receive buffers of 3/4 batch: the exchange of every batch takes
+    several rounds on both ranks; the run must end (no rank waits in a collective the other never enters) and
+    every other barrier must still fire exactly once."""
+    import torch.multiprocessing as mp
+    port = 35500 + os.getpid() % 2000
+    mp.spawn(worker, args=(port, str(tmp_path), ("--hot-frac", "0.5", "--recv-cap", str(NB * 3 // 4), "--no-profile")),
+             nprocs=2, join=True)
+    lines = [ln for ln in open(tmp_path / "out_0.txt").read().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    # barriers that lost a position to the hot key never complete; the others fire once per job
+    assert 0 < out["continuations_fired"] < 2 * NB * (STEPS // 8)

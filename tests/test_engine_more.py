@@ -1,6 +1,8 @@
 """More GPU checks through the C ABI: output caps of the sweep, the routing partition kernel,
 BASELINE config #3's shape (Zipf counts, 30 % expire through the timeout sweep) against the
 oracle, and config #2 at full size through size-independent properties."""
+import os
+
 import numpy as np
 import pytest
 
@@ -932,3 +934,70 @@ def test_replay_storm_at_full_batch_size(hot_mode):
         assert int(d_status[0]) == capi.DJ_JOIN_COMPLETE
     finally:
         e.close()
+
+
+def test_native_router_single_rank_roundtrip():
+    """The C router (dj_router_*: RCCL bound at run time, bucket sizes all-gathered, planned pieces) with one rank
+    and receive buffers smaller than the batch: every record and message comes back, in array order, over
+    several pieces."""
+    import ctypes
+    import torch
+    L = capi.load()
+    n, pitch, cap = 50_000, 64, 16_384
+    rng = np.random.default_rng(19)
+    e = _engine(capacity_barriers=64, arena_bytes=1 << 20, max_count=8, payload_stride=64, max_batch=1 << 16)
+    recs = torch.from_numpy(rng.integers(2, 1 << 62, (n, 4), dtype=np.int64)).to(e.device)
+    pay = torch.from_numpy(rng.integers(0, 256, (n, pitch), dtype=np.uint8)).to(e.device)
+    torch.cuda.synchronize()
+    uid = (ctypes.c_uint8 * 128)()
+    assert L.dj_route_unique_id(uid) == 0, L.dj_router_last_error(None)
+    r = ctypes.c_void_p()
+    assert L.dj_router_create(e.h, 1, 0, uid, n, cap, pitch, 2, ctypes.byref(r)) == 0, L.dj_router_last_error(None)
+    try:
+        for with_pay in (True, False):
+            h = ctypes.c_int(-1)
+            assert L.dj_route_start(r, n, recs.data_ptr(), pay.data_ptr() if with_pay else None, ctypes.byref(h)) == 0
+            got_r, got_p, pieces, more = [], [], 0, ctypes.c_int(1)
+            while more.value:
+                pr, pp, pn = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint32()
+                assert L.dj_route_next(r, h.value, ctypes.byref(pr), ctypes.byref(pp), ctypes.byref(pn), ctypes.byref(more)) == 0, \
+                    L.dj_router_last_error(r)
+                assert 0 < pn.value <= cap and bool(pp.value) == with_pay
+                # the engine's stream waits for the piece: once that stream has drained the piece is there; copy it
+                # out before the next one overwrites it
+                e.sync()
+                out_r = torch.empty((pn.value, 4), dtype=torch.int64, device=e.device)
+                assert capi_memcpy(out_r, pr.value, pn.value * 32)
+                got_r.append(out_r)
+                if with_pay:
+                    out_p = torch.empty((pn.value, pitch), dtype=torch.uint8, device=e.device)
+                    assert capi_memcpy(out_p, pp.value, pn.value * pitch)
+                    got_p.append(out_p)
+                pieces += 1
+            assert L.dj_route_release(r, h.value) == 0
+            assert pieces == -(-n // cap)
+            assert torch.equal(torch.cat(got_r), recs)
+            if with_pay:
+                assert torch.equal(torch.cat(got_p), pay)
+        # more batches in flight than buffer sets: refused, not overwritten
+        h1, h2, h3 = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        assert L.dj_route_start(r, 100, recs.data_ptr(), None, ctypes.byref(h1)) == 0
+        assert L.dj_route_start(r, 100, recs.data_ptr(), None, ctypes.byref(h2)) == 0
+        assert L.dj_route_start(r, 100, recs.data_ptr(), None, ctypes.byref(h3)) != 0
+        assert b"in use" in L.dj_router_last_error(r)
+    finally:
+        L.dj_router_destroy(r)
+        e.close()
+
+
+def capi_memcpy(dst_tensor, src_ptr, nbytes):
+    """device-to-device copy from a raw pointer into a tensor (synchronous)."""
+    import ctypes
+    import torch
+    hip = ctypes.CDLL(None)
+    fn = getattr(hip, "hipMemcpy", None)
+    if fn is None:
+        hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+        fn = hip.hipMemcpy
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    return fn(dst_tensor.data_ptr(), src_ptr, nbytes, 3) == 0      # hipMemcpyDeviceToDevice

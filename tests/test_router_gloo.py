@@ -2,6 +2,9 @@
 all-to-all-v (distributed_join_amd.router.exchange) and apply it to a per-rank store; the union
 of what the ranks fire must equal what one store fires on the whole stream.
 
+Half of every rank's events go to ONE barrier (a hot key): its owner receives far more rows than its
+receive buffer holds (RECV_CAP), so the exchange takes several rounds, planned identically on both ranks.
+
 The HIP partition kernel (dj_partition_joins) is replaced here by a numpy stable partition with
 the same contract; the per-rank store is the CPU oracle (this is a test of the routing layer,
 the GPU parity tests cover the engine)."""
@@ -15,6 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORLD = 2
 NB, C, P = 600, 5, 64
 T0 = 1_700_000_000_000
+HOT = WORLD * NB      # an extra barrier that receives as many events again as all others (positions 0..C-2: never complete)
+RECV_CAP = 1000       # rows per round a rank can take: the hot key's owner needs several rounds
 
 
 def gen_stream(rank):
@@ -24,8 +29,11 @@ def gen_stream(rank):
     ev = np.concatenate([ev, ev[rng.integers(0, NB * C, 40)]])      # at-least-once replays
     b = ev // C + rank * NB
     pos = ev % C
+    hot_at = np.sort(rng.integers(0, len(b) + 1, len(b)))          # hot events sprinkled through the stream
+    b = np.insert(b, hot_at, HOT)
+    pos = np.insert(pos, hot_at, rng.integers(0, C - 1, len(hot_at)))
     from tests.parity import payload_bytes
-    pay = payload_bytes(b, pos, np.arange(len(ev)) + 7 * rank, P)
+    pay = payload_bytes(b, pos, np.arange(len(b)) + 7 * rank, P)
     return b, pos, pay
 
 
@@ -46,7 +54,7 @@ def worker(rank, port, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
-    ids = [f"j{b:x}~t{b:x}" for b in range(WORLD * NB)]
+    ids = [f"j{b:x}~t{b:x}" for b in range(WORLD * NB + 1)]
     fps = capi.fingerprint_many(ids)
     owners_all = owner_of_np(fps[:, 1], WORLD)
     assert all(capi.owner_of(int(lo), int(hi), WORLD) == int(o) for (lo, hi), o in zip(fps[:64], owners_all[:64]))
@@ -57,24 +65,31 @@ def worker(rank, port, out_dir):
         order, counts = stable_partition(own, WORLD)
         rs = torch.from_numpy(recs[order].copy())
         ps = torch.from_numpy(pay[order].copy()) if pay is not None else None
-        rr = torch.zeros((len(recs) * WORLD + 64, recs.shape[1]), dtype=torch.int64)
-        rp = torch.zeros((len(recs) * WORLD + 64, P), dtype=torch.uint8) if pay is not None else None
-        n_in, rc = exchange(dist, dist.group.WORLD, rs, ps, counts, rr, rp)
-        assert n_in == sum(rc)
-        got = rr[:n_in].numpy()
+        rr = torch.zeros((RECV_CAP, recs.shape[1]), dtype=torch.int64)
+        rp = torch.zeros((RECV_CAP, P), dtype=torch.uint8) if pay is not None else None
+        pieces = exchange(dist, dist.group.WORLD, rs, ps, counts, rr, rp)
+        rounds.append(len(pieces))
+        got = np.concatenate([x[1].numpy() for x in pieces])
         assert (owners_all[got[:, 0]] == rank).all()                # only my barriers arrive
-        return got, (rp[:n_in].numpy() if pay is not None else None)
+        return got, (np.concatenate([x[2].numpy() for x in pieces]) if pay is not None else None)
+
+    rounds = []
 
     # forks: every rank forks its own id range, routed to the owners
-    mine = np.arange(rank * NB, (rank + 1) * NB)
-    frecs = np.stack([mine, np.full(NB, C)], axis=1).astype(np.int64)
+    mine = np.arange(rank * NB, (rank + 1) * NB + (1 if rank == WORLD - 1 else 0))       # the last rank also forks the hot one
+    frecs = np.stack([mine, np.full(len(mine), C)], axis=1).astype(np.int64)
     fr, _ = route(frecs, None)
     o.fork_batch(fr[:, 0], fr[:, 1], np.full(len(fr), T0 + 3_600_000))
     b, pos, pay = gen_stream(rank)
     jr, jp = route(np.stack([b, pos], axis=1).astype(np.int64), pay)
+    assert rounds[-1] >= 2, "the hot key's owner must have needed more than one round (on both ranks the same number)"
     o.join_batch(jr[:, 0], jr[:, 1], np.full(len(jr), P), np.zeros(len(jr)), jp, T0 + 5)
+    hot_mine = owners_all[HOT] == rank
+    hm, hl, _, hp = o.snapshot_one(HOT) if hot_mine else (None, None, None, None)
     conts, lens, mws, payo = o.sweep(T0 + 10, cap_conts=4096, cap_positions=4096 * C)
     fired = {}
+    if hot_mine:         # what the hot barrier holds position by position (last writer in the global order)
+        fired["hot"] = [bytes(hp[p, :int(hl[p])]) if int(hl[p]) != 0xFFFFFFFF else None for p in range(C)]
     for c in conts:
         pb = int(c["pos_base"])
         fired[int(c["id_idx"])] = (int(c["flags"]), [bytes(payo[pb + p, :int(lens[pb + p])]) for p in range(C)])
@@ -93,16 +108,17 @@ def test_two_ranks_fire_what_one_store_fires(tmp_path, oracle_lib):
         assert not (fired.keys() & part.keys()), "a barrier fired on two ranks"
         fired.update(part)
     # the same global stream on one store: rank 0's events first, then rank 1's
-    ids = [f"j{b:x}~t{b:x}" for b in range(WORLD * NB)]
+    ids = [f"j{b:x}~t{b:x}" for b in range(WORLD * NB + 1)]
     o = oracle_lib.Oracle(ids, max_count=C, payload_stride=P)
-    o.fork_batch(np.arange(WORLD * NB), np.full(WORLD * NB, C), np.full(WORLD * NB, T0 + 3_600_000))
+    o.fork_batch(np.arange(WORLD * NB + 1), np.full(WORLD * NB + 1, C), np.full(WORLD * NB + 1, T0 + 3_600_000))
     for r in range(WORLD):
         b, pos, pay = gen_stream(r)
         o.join_batch(b, pos, np.full(len(b), P), np.zeros(len(b)), pay, T0 + 5)
+    hm, hl, _, hp = o.snapshot_one(HOT)
     conts, lens, mws, payo = o.sweep(T0 + 10, cap_conts=4096, cap_positions=4096 * C)
-    want = {}
+    want = {"hot": [bytes(hp[p, :int(hl[p])]) if int(hl[p]) != 0xFFFFFFFF else None for p in range(C)]}
     for c in conts:
         pb = int(c["pos_base"])
         want[int(c["id_idx"])] = (int(c["flags"]), [bytes(payo[pb + p, :int(lens[pb + p])]) for p in range(C)])
-    assert len(want) == WORLD * NB
+    assert len(want) == WORLD * NB + 1          # every barrier but the hot one fires, plus the hot one's snapshot
     assert fired == want

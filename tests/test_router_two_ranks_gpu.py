@@ -1,9 +1,11 @@
 """The N>1 path with two PROCESSES that each drive an engine on the GPU (both on device 0: the box
-has one): every rank partitions its event stream with the HIP kernels (dj_partition_joins),
-the buckets cross ranks with the router's all-to-all-v over gloo (staged through host memory
-here, because two ranks of one RCCL communicator cannot share a device), and each rank applies
-what it owns.  The union of what the two engines fire must be what the oracle fires on the whole
-stream in the router's global order (rank 0's events, then rank 1's)."""
+has one): every rank routes its event stream with the Router (HIP partition kernels, dj_partition_joins; the
+buckets cross ranks with the planned all-to-all-v over gloo, staged through host memory here because
+two ranks of one RCCL communicator cannot share a device), and each rank applies what it owns.  One
+barrier receives as many events again as all the others together, so its owner takes its rows in several
+rounds (the receive buffers hold MAX_RECV rows).  The union of what the two engines fire, and what the hot
+barrier holds, must be what the oracle has after the whole stream in the router's global order (rank 0's
+events, then rank 1's)."""
 import os
 import sys
 
@@ -15,6 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORLD = 2
 NB, C, P = 3000, 6, 64
 T0 = 1_700_000_000_000
+HOT = WORLD * NB      # the hot barrier's index (positions 0..C-2 only: it never completes)
+MAX_RECV = 8192
 
 
 def gen_stream(rank):
@@ -23,8 +27,11 @@ def gen_stream(rank):
     ev = np.concatenate([ev, ev[rng.integers(0, NB * C, 300)]])      # replays: last writer wins
     b = ev // C + rank * NB
     pos = ev % C
+    hot_at = np.sort(rng.integers(0, len(b) + 1, len(b)))
+    b = np.insert(b, hot_at, HOT)
+    pos = np.insert(pos, hot_at, rng.integers(0, C - 1, len(hot_at)))
     from tests.parity import payload_bytes
-    return b, pos, payload_bytes(b, pos, np.arange(len(ev)) + 11 * rank, P)
+    return b, pos, payload_bytes(b, pos, np.arange(len(b)) + 11 * rank, P)
 
 
 def worker(rank, port, out_dir):
@@ -33,61 +40,70 @@ def worker(rank, port, out_dir):
     import torch.distributed as dist
     from distributed_join_amd import capi
     from distributed_join_amd.engine import Engine
-    from distributed_join_amd.router import exchange
+    from distributed_join_amd.router import Router
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=WORLD)
     dev = torch.device("cuda", 0)
-    e = Engine(capacity_barriers=WORLD * NB, arena_bytes=64 << 20, max_count=C, payload_stride=P, max_batch=1 << 16,
+    e = Engine(capacity_barriers=WORLD * NB + 1, arena_bytes=64 << 20, max_count=C, payload_stride=P, max_batch=1 << 16,
                host_cap_conts=1 << 14, host_cap_positions=1 << 17)
-    ids = [f"j{b:x}~t{b:x}" for b in range(WORLD * NB)]
+    ids = [f"j{b:x}~t{b:x}" for b in range(WORLD * NB + 1)]
     fps = capi.fingerprint_many(ids)
+    router = Router(e, dist.group.WORLD, max_send=1 << 16, max_recv=MAX_RECV, pitch=P)
+    rounds = []
 
-    def route(recs, pay):
-        """recs: structured FORK_REC / JOIN_REC array; -> (records owned by this rank, their messages)"""
-        n = len(recs)
-        d_recs = torch.from_numpy(recs.view(np.uint8).reshape(-1).copy()).to(dev)
+    def routed(recs, pay, apply):
+        """Route a structured FORK_REC / JOIN_REC array; apply(records, messages, n) runs once per piece."""
+        d_recs = torch.from_numpy(recs.view(np.uint8).reshape(-1).copy()).to(dev).view(torch.int64).reshape(len(recs), 4)
         d_pay = torch.from_numpy(pay).to(dev) if pay is not None else None
-        d_ro = torch.empty_like(d_recs)
-        d_po = torch.empty_like(d_pay) if pay is not None else None
-        d_origin = torch.empty(n, dtype=torch.int32, device=dev)
-        d_counts = torch.zeros(64, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
-        e.partition_joins_dev(n, WORLD, d_recs, d_pay, P, d_ro, d_po, d_origin, d_counts)
-        e.sync()
-        counts = d_counts.cpu().tolist()[:WORLD]
-        rs = d_ro.cpu().view(torch.int64).reshape(n, 4)
-        ps = d_po.cpu() if pay is not None else None
-        rr = torch.zeros((n * WORLD + 64, 4), dtype=torch.int64)
-        rp = torch.zeros((n * WORLD + 64, P), dtype=torch.uint8) if pay is not None else None
-        n_in, rc = exchange(dist, dist.group.WORLD, rs, ps, counts, rr, rp)
-        return rr[:n_in].contiguous(), (rp[:n_in].contiguous() if pay is not None else None), n_in
+        h = router.start(d_recs, d_pay, len(recs))
+        r_recs, r_pay, n_in = router.finish(h)
+        k = 1
+        apply(r_recs, r_pay, n_in)
+        while router.more(h):
+            r_recs, r_pay, n_in = router.next_round(h)
+            apply(r_recs, r_pay, n_in)
+            k += 1
+        router.release(h)
+        rounds.append(k)
 
-    mine = np.arange(rank * NB, (rank + 1) * NB)
-    frecs = np.zeros(NB, dtype=capi.FORK_REC)
+    mine = np.arange(rank * NB, (rank + 1) * NB + (1 if rank == WORLD - 1 else 0))
+    frecs = np.zeros(len(mine), dtype=capi.FORK_REC)
     frecs["fp_lo"], frecs["fp_hi"], frecs["count"], frecs["deadline_ms"] = fps[mine, 0], fps[mine, 1], C, T0 + 3_600_000
-    fr, _, n_f = route(frecs, None)
-    st = e.fork_batch(fr.numpy().view(capi.FORK_REC).reshape(-1))
-    assert (st == capi.DJ_FORK_CREATED).all()
+    d_st = e.empty(MAX_RECV * 4)
+
+    def apply_forks(r_recs, r_pay, n):
+        e.fork_batch_dev(n, r_recs, d_st)
+        e.sync()
+        assert (d_st[:n * 4].view(torch.int32) == capi.DJ_FORK_CREATED).all()
+
+    routed(frecs, None, apply_forks)
     b, pos, pay = gen_stream(rank)
     jrecs = np.zeros(len(b), dtype=capi.JOIN_REC)
     jrecs["fp_lo"], jrecs["fp_hi"], jrecs["position"], jrecs["len"] = fps[b, 0], fps[b, 1], pos, P
-    jr, jp, n_j = route(jrecs, pay)
-    got = jr.numpy().view(capi.JOIN_REC).reshape(-1)
-    assert all(capi.owner_of(int(r["fp_lo"]), int(r["fp_hi"]), WORLD) == rank for r in got[:200])
-    d_st = e.empty(n_j * 4)
-    e.join_batch_dev(n_j, jr.to(dev), jp.to(dev), P, T0 + 5, d_st)
+
+    def apply_joins(r_recs, r_pay, n):
+        got = r_recs[:min(n, 200)].cpu().numpy().view(capi.JOIN_REC).reshape(-1)
+        assert all(capi.owner_of(int(r["fp_lo"]), int(r["fp_hi"]), WORLD) == rank for r in got)
+        e.join_batch_dev(n, r_recs, r_pay, P, T0 + 5, d_st)
+
+    routed(jrecs, pay, apply_joins)
     e.sync()
+    by_fp = {(int(lo), int(hi)): k for k, (lo, hi) in enumerate(fps)}
+    fired = {"rounds": rounds[-1]}
+    if capi.owner_of(int(fps[HOT, 0]), int(fps[HOT, 1]), WORLD) == rank:
+        _, hl, _, hp = e.snapshot_one(fps[HOT, 0], fps[HOT, 1])
+        fired["hot"] = [bytes(hp[p, :int(hl[p])]) if int(hl[p]) != capi.DJ_NIL else None for p in range(C)]
     conts, lens, _, payo, more = e.sweep(T0 + 10)
     assert not more
-    by_fp = {(int(lo), int(hi)): k for k, (lo, hi) in enumerate(fps)}
-    fired = {}
     for c in conts:
         pb = int(c["pos_base"])
         fired[by_fp[(int(c["fp_lo"]), int(c["fp_hi"]))]] = (
             int(c["flags"]), [bytes(payo[pb + p, :int(lens[pb + p])]) for p in range(C)])
     np.save(os.path.join(out_dir, f"fired_{rank}.npy"), np.array([fired], dtype=object), allow_pickle=True)
+    del router
     e.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -100,18 +116,20 @@ def test_two_engine_processes_fire_what_one_store_fires(tmp_path, oracle_lib):
     fired = {}
     for r in range(WORLD):
         part = np.load(tmp_path / f"fired_{r}.npy", allow_pickle=True)[0]
+        assert part.pop("rounds") >= 2, "the hot barrier's owner needs several rounds, and so every rank takes part in them"
         assert not (fired.keys() & part.keys()), "a barrier fired on two ranks"
         fired.update(part)
-    ids = [f"j{b:x}~t{b:x}" for b in range(WORLD * NB)]
+    ids = [f"j{b:x}~t{b:x}" for b in range(WORLD * NB + 1)]
     o = oracle_lib.Oracle(ids, max_count=C, payload_stride=P)
-    o.fork_batch(np.arange(WORLD * NB), np.full(WORLD * NB, C), np.full(WORLD * NB, T0 + 3_600_000))
+    o.fork_batch(np.arange(WORLD * NB + 1), np.full(WORLD * NB + 1, C), np.full(WORLD * NB + 1, T0 + 3_600_000))
     for r in range(WORLD):
         b, pos, pay = gen_stream(r)
         o.join_batch(b, pos, np.full(len(b), P), np.zeros(len(b)), pay, T0 + 5)
+    _, hl, _, hp = o.snapshot_one(HOT)
     conts, lens, mws, payo = o.sweep(T0 + 10, cap_conts=1 << 14, cap_positions=1 << 17)
-    want = {}
+    want = {"hot": [bytes(hp[p, :int(hl[p])]) if int(hl[p]) != 0xFFFFFFFF else None for p in range(C)]}
     for c in conts:
         pb = int(c["pos_base"])
         want[int(c["id_idx"])] = (int(c["flags"]), [bytes(payo[pb + p, :int(lens[pb + p])]) for p in range(C)])
-    assert len(want) == WORLD * NB
+    assert len(want) == WORLD * NB + 1
     assert fired == want
