@@ -37,6 +37,11 @@ def parse():
     ap.add_argument("--count", type=int, default=8)
     ap.add_argument("--payload", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--min-timed-ms", type=float, default=200.0,
+                    help="the K steps are repeated (whole multiples of K) until the timed region is at least this long")
+    ap.add_argument("--config3", type=int, default=-1,
+                    help="also run BASELINE configs[2] (Zipf counts, 30 %% of the barriers expire) with this many barriers and "
+                         "report it under 'config3' (default: 10 M at N=1 with default sizes, 0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--hot-frac", type=float, default=0.0,
                     help="experiment: retarget this fraction of the joins to ONE barrier (hot key, replays)")
@@ -154,6 +159,109 @@ def cpu_baseline_sharded(count, payload):
                       f"{count} batches, sweep + ack per batch"}
 
 
+def run_config3(torch, capi, Engine, dev, local, nb):
+    """BASELINE configs[2] on one GPU: nb barriers with counts Zipf(1) on [2, 64]; 30 % of them receive only a
+    strict subset of their positions and carry a deadline inside the run, so they leave through the timeout
+    sweep; batches of 2^22 joins in shuffled order, the clock advances with every batch; one sweep (pop +
+    gather) and the ack of everything popped per batch.  Timed: the fork of all barriers, every batch, and the
+    sweeps after the last batch that catch the remaining deadlines.  All inputs are generated in HBM beforehand."""
+    P, batch = 64, 1 << 22
+    T0 = 1_700_000_000_000
+    t_gen = time.perf_counter()
+    rng = np.random.default_rng(3)
+    fps = torch.from_numpy(capi.fingerprint_many([f"j{b:x}~t{b:x}" for b in range(nb)]).view(np.int64)).to(dev)
+    k = np.arange(2, 65)
+    counts = torch.from_numpy(rng.choice(k, size=nb, p=(1.0 / k) / (1.0 / k).sum())).to(dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    offsets = torch.cumsum(counts, 0) - counts
+    cells = int(counts.sum())
+    expire = torch.rand(nb, device=dev, generator=g) < 0.3
+    cell_b = torch.repeat_interleave(torch.arange(nb, device=dev), counts)
+    cell_p = torch.arange(cells, device=dev) - offsets[cell_b]
+    # an expiring barrier never gets one (hashed) position and each of its others with probability 1/2
+    never = (cell_b * 2654435761 >> 7) % counts[cell_b]
+    sent = ~expire[cell_b] | ((cell_p != never) & (torch.rand(cells, device=dev, generator=g) < 0.5))
+    ev = torch.nonzero(sent).reshape(-1)
+    ev = ev[torch.randperm(len(ev), device=dev, generator=g)]
+    n_events = len(ev)
+    n_batches = (n_events + batch - 1) // batch
+    deadline = torch.where(expire, T0 + 11 + 2 * torch.randint(0, n_batches, (nb,), device=dev, generator=g),
+                           torch.full((nb,), T0 + 30 * 86_400_000, device=dev))
+    frecs = torch.empty((nb, 4), dtype=torch.int64, device=dev)
+    frecs[:, 0], frecs[:, 1], frecs[:, 2], frecs[:, 3] = fps[:, 0], fps[:, 1], counts, deadline
+    recs = torch.empty((n_events, 4), dtype=torch.int64, device=dev)
+    jb, jp = cell_b[ev], cell_p[ev]
+    recs[:, 0], recs[:, 1], recs[:, 2], recs[:, 3] = fps[jb, 0], fps[jb, 1], jp | (P << 32), 0
+    del cell_b, cell_p, never, sent, ev, jb, jp, fps, offsets
+    pay = torch.randint(0, 256, (batch, P), dtype=torch.uint8, device=dev, generator=g)     # the same bytes for every batch
+    slots_pow2 = 1 << (2 * nb - 1).bit_length()
+    eng = Engine(capacity_barriers=nb, arena_bytes=int(cells * 1.6 * (P + 8)) + nb * 128 + (256 << 20), max_count=64,
+                 payload_stride=P, max_batch=max(nb, batch), device=local)
+    # most barriers complete in the last batches (a barrier is complete when the LAST of its shuffled positions
+    # arrives), so one sweep may pop a large share of them: buffers for all of them, no sweep is ever cut short
+    cap_c = nb + 1024
+    cap_p = cells + 64
+    d_conts, d_lens, d_out = eng.empty(cap_c * 64), eng.empty(cap_p * 4), eng.empty(cap_p * P)
+    d_res = torch.zeros((n_batches + 16, 4), dtype=torch.int32, device=dev)
+    d_st = eng.empty(max(nb, batch) * 4)
+    d_ack = eng.empty(cap_c * 4)
+    d_fst = eng.empty(nb * 4)
+    torch.cuda.synchronize()
+    gen_s = time.perf_counter() - t_gen
+
+    def job(profile):
+        acc = {}
+        sweeps = 0
+
+        def read():
+            if profile:
+                for name, ms in eng.profile_read().items():
+                    acc.setdefault(name, []).append(ms)
+
+        eng.fork_batch_dev(nb, frecs, d_fst)
+        read()
+        for k in range(n_batches + 8):
+            now = T0 + 2 * (k + 1)
+            if k < n_batches:
+                lo = k * batch
+                n = min(batch, n_events - lo)
+                eng.join_batch_dev(n, recs[lo:lo + n], pay, P, now, d_st)
+            eng.sweep_dev(now, cap_c, cap_p, d_conts, d_lens, None, d_out, d_res[k])
+            eng.ack_batch_dev(cap_c, d_res[k], d_conts, None, now, d_ack)
+            sweeps += 1
+            read()
+        return acc, sweeps
+
+    job(False)                                     # warm-up: a whole job (the table is empty again afterwards)
+    eng.sync()
+    st = d_fst[:nb * 4].view(torch.int32)
+    assert bool((st == capi.DJ_FORK_CREATED).all()), f"config 3: forks refused: {torch.unique(st, return_counts=True)}"
+    assert int(d_res[:, 0].to(torch.int64).sum()) == nb and not int(d_res[:, 1].sum()), \
+        f"config 3 warm-up: {int(d_res[:, 0].to(torch.int64).sum())} of {nb} barriers fired, more flags {d_res[:, 1].tolist()}"
+    d_res.zero_()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    _, sweeps = job(False)
+    eng.sync()
+    dt = time.perf_counter() - t0
+    fired = int(d_res[:, 0].to(torch.int64).sum())
+    assert fired == nb, (fired, nb)
+    eng.profile_enable(True)
+    acc, _ = job(True)
+    eng.profile_enable(False)
+    kern = {name: {"avg_ms": round(sum(v) / len(v), 4), "launches": len(v), "total_ms": round(sum(v), 3)} for name, v in acc.items()}
+    n_timeout = int(expire.sum())
+    out = {"workload": f"configs[2]: {nb} barriers, counts Zipf(1) on [2, 64] ({cells} positions), 30 % ({n_timeout}) expire "
+                       f"through the timeout sweep with a strict subset of their positions, {P} B messages, {n_batches} batches "
+                       f"of {batch} joins + sweep/gather + ack each, clock +2 ms per batch, fork of all barriers included",
+           "value": n_events / dt, "unit": "join events/s", "join_events": n_events, "job_ms": dt * 1e3,
+           "continuations_per_s": nb / dt, "continuations_fired": fired, "complete": nb - n_timeout, "timeout": n_timeout,
+           "sweeps": sweeps, "table_slots": slots_pow2, "generation_s": round(gen_s, 1), "kernels": kern}
+    eng.close()
+    return out
+
+
 def main():
     a = parse()
     import torch
@@ -255,6 +363,7 @@ def main():
 
     def step(k, prefetch=2):
         """One step: (fork at job start) + join batch + sweep + ack."""
+        nonlocal d_res_all
         s = k % steps_per_job
         now[0] += 1
         dbg("step", k)
@@ -283,7 +392,7 @@ def main():
                 r_recs, r_pay, n_in = router.next_round(h)
                 eng.join_batch_dev(n_in, r_recs, r_pay, pitch, now[0], d_status)
             router.release(h)
-        d_res = d_res_all[res_i[0] % res_cap]
+        d_res = d_res_all[res_i[0] % d_res_all.shape[0]]
         res_i[0] += 1
         eng.sweep_dev(now[0], cap_conts, cap_pos, d_conts, d_lens, None, d_pay_out, d_res)
         eng.ack_batch_dev(cap_conts, d_res, d_conts, None, now[0], d_ack_status)
@@ -320,14 +429,32 @@ def main():
     barrier()
     torch.cuda.synchronize()
 
+    # how many times the K steps are repeated: the timed region should last at least --min-timed-ms (a few
+    # milliseconds of kernels would be inside the noise of one box); decided from a trial job, the same on every rank
+    t_trial = time.perf_counter()
+    for k in range(steps_per_job):
+        step(warm + k, prefetch=min(2, steps_per_job - 1 - k))
+    barrier()
+    trial = torch.tensor([(time.perf_counter() - t_trial) / steps_per_job], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(trial, op=dist.ReduceOp.MAX)
+    warm += steps_per_job
+    repeats = max(1, int(np.ceil(1.1 * a.min_timed_ms * 1e-3 / (float(trial.item()) * a.steps))))
+    timed_steps = repeats * a.steps
+    res_cap_needed = timed_steps + 8
+    if res_cap_needed > d_res_all.shape[0]:
+        d_res_all = torch.zeros((res_cap_needed, 4), dtype=torch.int32, device=dev)
+        res_cap = res_cap_needed
+    res_i[0] = 0
+
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     res_first = res_i[0]
     t0 = time.perf_counter()
     ev0.record(es)
-    for k in range(a.steps):
+    for k in range(timed_steps):
         # step numbers go on from the warm-up's (whole jobs): a barrier forked once stays forked once
-        step(warm + k, prefetch=min(2, a.steps - 1 - k))
+        step(warm + k, prefetch=min(2, timed_steps - 1 - k))
     ev1.record(es)
     barrier()
     wall = time.perf_counter() - t0
@@ -346,16 +473,16 @@ def main():
     acc = {}
     if not a.no_profile:
         # every rank runs these steps (the routed path is a collective); only rank 0 times its kernels
-        done = a.steps
+        done = timed_steps
         # finish the job in flight so the profiled job starts on an empty table
         while done % steps_per_job:
-            step(done, prefetch=0)
+            step(warm + done, prefetch=0)
             done += 1
         eng.sync()
         if rank == 0:
             eng.profile_enable(True)
         for k in range(steps_per_job):
-            step(k + steps_per_job, prefetch=0)      # not the first job: a hot key, if any, is not forked again
+            step(warm + done + k, prefetch=0)        # not the first job: a hot key, if any, is not forked again
             if rank == 0:
                 for name, ms in eng.profile_read().items():
                     acc.setdefault(name, []).append(ms)
@@ -386,6 +513,10 @@ def main():
             traffic = traffic_detail.get("hbm_bytes") if traffic_detail else None     # HBM bytes per launch
         roofline = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["achieved_GBps"], "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(kernels[dom]["achieved_GBps"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                    "traffic_source": (None if traffic is None else
+                                       "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload "
+                                       "collected in an earlier run (" + str((traffic_detail or {}).get("collected", "round 1, profile set g")) +
+                                       "), average per launch; not measured in this run"),
                     "avg_launch_ms": kernels[dom]["avg_ms"],
                     "alg_bytes_per_launch": kernels[dom]["alg_bytes_per_launch"], "traffic_detail": traffic_detail}
         # measured streaming ceiling of this GPU beside the spec peak: device-to-device copy of 1 GiB
@@ -405,16 +536,35 @@ def main():
                                  "achieved_GBps": round((112 + 2 * P) * batch / (jt * 1e-3) / 1e9, 1),
                                  "frac": round((112 + 2 * P) * batch / (jt * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
 
+    if roofline is not None:
+        # the whole step against the end-to-end figure of one join event on a fire-everything stream:
+        # 112 + 4P + 256/c bytes (join path 112 + 2P, gather 2P + 96/c, insert 160/c)
+        step_bytes = 112 + 4 * P + 256.0 / c
+        step_gbps = step_bytes * batch / (elapsed_s / timed_steps) / 1e9
+        roofline["step"] = {"alg_bytes_per_event": round(step_bytes, 1), "ms_per_step": round(elapsed_s * 1e3 / timed_steps, 4),
+                            "achieved_GBps": round(step_gbps, 1), "frac": round(step_gbps / HBM_PEAK_GBPS, 4)}
+
+    c3 = None
+    n_c3 = a.config3 if a.config3 >= 0 else (10_000_000 if (world == 1 and not routed and (nb, c, P) == (1 << 20, 8, 64)
+                                                            and not a.hot_frac and not a.zipf_frac) else 0)
+    if n_c3 and world == 1:
+        eng.close()
+        eng = None
+        del payloads, recs, fork_recs, d_conts, d_lens, d_pay_out
+        torch.cuda.empty_cache()
+        c3 = run_config3(torch, capi, Engine, dev, local, n_c3)
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(c, P)
 
     if rank == 0:
-        total_events = a.steps * batch * world
+        total_events = timed_steps * batch * world
         out = {
             "metric": "join events/sec + continuations fired/sec at 1/2/4/8 GPUs; % HBM roofline",
             "value": total_events / elapsed_s, "unit": "join events/s", "n_gpus": world, "steps": a.steps,
-            "warmup": warm, "ms_per_step": elapsed_s * 1e3 / a.steps, "higher_is_better": True,
+            "warmup": warm, "ms_per_step": elapsed_s * 1e3 / timed_steps, "higher_is_better": True,
+            "repeats": repeats, "timed_steps": timed_steps, "timed_region_ms": elapsed_s * 1e3,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64 (integer and byte work)", "data": "synthetic",
             "config": {"workload": f"configs[1]: {nb} barriers x count {c} per GPU, {P} B messages, uniform arrival, "
                                    f"no timeouts; step = {batch} joins + sweep/gather + ack, fork of {nb} barriers every "
@@ -425,12 +575,13 @@ def main():
             "continuations_per_s": float(fired.item()) / elapsed_s,
             "continuations_fired": int(fired.item()),
             "gpu_stream_ms": gpu_ms,
-            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu,
+            "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "config3": c3,
         }
         print(json.dumps(out))
     if routed:
         dist.destroy_process_group()
-    eng.close()
+    if eng is not None:
+        eng.close()
 
 
 if __name__ == "__main__":
