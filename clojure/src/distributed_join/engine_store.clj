@@ -72,7 +72,9 @@
 
 (def ^:private payload-stride (long (or (:engine-payload-stride env) 256)))
 (def ^:private max-count (long (:fork-count-max env)))                 ; config.edn:33
-(def ^:private max-message (long (:join-message-len-max env)))         ; config.edn:38
+(def ^:private max-message (long (:join-message-len-max env)))         ; config.edn:38, in characters (store.clj:24-26)
+;; the engine stores UTF-8 bytes: at most three per UTF-16 code unit of a String
+(def ^:private max-message-bytes (long (min (* 3 max-message) (bit-shift-left 1 20))))
 (def ^:private sweep-cap (long (or (:engine-sweep-cap env) 65536)))    ; continuations per poll
 
 (defn- make-config ^Memory []
@@ -87,7 +89,7 @@
     (.setInt 32 (int (or (:engine-max-batch env) (bit-shift-left 1 20))))
     (.setInt 36 (int (:max-retry-post-publish env)))                   ; config.edn:24
     (.setInt 40 (int (:max-retry-post-timeout-publish env)))           ; config.edn:25
-    (.setInt 44 (int (min max-message (bit-shift-left 1 20))))
+    (.setInt 44 (int max-message-bytes))
     (.setLong 48 (long (:check-publish-delay-ms env)))))               ; config.edn:16
 
 (defonce ^:private engine
@@ -100,7 +102,7 @@
                      (.setInt 0 (int 16))
                      (.setInt 4 (int (or (:engine-batcher-max-batch env) 65536)))
                      (.setInt 8 (int (or (:engine-batcher-linger-us env) 100)))
-                     (.setInt 12 (int (min max-message (bit-shift-left 1 20)))))
+                     (.setInt 12 (int max-message-bytes)))
                ref (PointerByReference.)]
            (check (native-int dj "dj_batcher_create" @engine cfg ref) "dj_batcher_create")
            (.getValue ref))))

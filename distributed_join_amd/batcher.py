@@ -74,6 +74,13 @@ class Batcher:
         self._check(self.L.dj_batcher_join(self.h, r.ctypes.data_as(ctypes.c_void_p),
                                            ctypes.cast(buf, ctypes.c_void_p) if buf is not None else None, cb, None))
 
+    def fork_async(self, fp, count, deadline_ms, on_status):
+        """on_status(status) runs on the drain thread."""
+        r = self._fork_rec(fp, count, deadline_ms)
+        cb = capi.STATUS_CB(lambda _u, st: on_status(int(st)))
+        self._keep.append(cb)
+        self._check(self.L.dj_batcher_fork(self.h, r.ctypes.data_as(ctypes.c_void_p), cb, None))
+
     def run(self, fn):
         """fn(now_ms) -> int runs on the drain thread between two batches, with the engine idle."""
         out = {}

@@ -9,7 +9,7 @@ the reference's timing-sensitive tests become deterministic scenarios.
 
 What stays on the host, as in the reference: id strings, destination URLs, validation.
 """
-from . import capi
+from . import capi, edn
 from .store import DEFAULT_ENV, validate_fork, validate_join
 
 # HTTP answers (http_handling.clj:27-36)
@@ -24,7 +24,7 @@ class ForkJoinService:
     def __init__(self, store, clock, post, env=None):
         self.store = store
         self.clock = clock            # () -> epoch ms   (time_util.clj:3-4)
-        self.post = post              # (url, body_dict) -> response, raises on failure
+        self.post = post              # (url, body bytes, content type) -> response, raises on failure (publish.clj:6-15)
         self.env = dict(DEFAULT_ENV)
         if env:
             self.env.update(env)
@@ -111,10 +111,11 @@ class ForkJoinService:
                                            "happen. The fork will be completed as failed."))
                 oks.append(False)
                 continue
-            body = {"barrier-id": c.barrier_id,
-                    "messages": [None if m is None else m.decode() for m in c.messages]}   # core.clj:165-166
+            # {:barrier-id id :messages (map :message joins)} (core.clj:165-166) as the EDN bytes aleph sends for
+            # :form-params with :content-type :application/edn (publish.clj:9-11)
+            body = edn.encode(c.barrier_id, [None if m is None else m.decode() for m in c.messages])
             try:
-                results.append(self.post(self._destination(c), body))
+                results.append(self.post(self._destination(c), body, edn.CONTENT_TYPE))
                 oks.append(True)
             except Exception as ex:      # core.clj:167,170: any failure goes to attempt-retry-publish
                 results.append(ex)

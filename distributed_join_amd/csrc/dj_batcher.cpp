@@ -1,10 +1,20 @@
 // dj_batcher.cpp — per-request front of the engine (include/dj_batcher.h).
 //
-// Producers (request threads) fill one of two staging sets under a mutex; the drain thread swaps
-// the sets, ships the closed one to the device from pinned memory, applies it and answers.  The
-// drain thread is the only caller of the engine.
+// Producers (request threads) stage their requests in LANES: a thread is given a lane on its first call
+// and only ever takes that lane's (uncontended) lock, so staging costs no shared cache line.  A lane has
+// two sides; the drain thread closes every lane's filling side at once (a window), gathers the closed
+// sides into pinned buffers, ships them to the device, applies them and answers.  The drain thread is the
+// only caller of the engine.
+//
+// Order.  Requests of one lane are applied in the order they were staged: a window is cut into phases
+// (forks of phase p, then joins of phase p, then phase p + 1 ...) and a lane starts a new phase whenever it
+// stages a fork of a barrier that has a join waiting in its current phase, so "join, then fork of the same
+// id" keeps that order although the engine applies forks and joins as separate batches.  Requests of
+// different lanes that were staged in the same window are concurrent requests: any interleaving is a valid
+// serialisation.  A request staged after another one was ANSWERED is applied in a later window.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
@@ -16,6 +26,8 @@
 #include "dj_batcher.h"
 
 namespace {
+
+constexpr int LANES = 64;
 
 struct Waiter {              // a caller blocked in *_wait / run
     int32_t status = 0;
@@ -33,13 +45,60 @@ struct Answer {
     void* user;
 };
 
-struct Side {
-    dj_join_rec* jrecs = nullptr;   // pinned
-    uint8_t* jpay = nullptr;        // pinned, max_batch * pitch
-    dj_fork_rec* frecs = nullptr;   // pinned
-    std::vector<Answer> jans, fans;
-    uint32_t nj = 0, nf = 0;
-    std::vector<Task> tasks;
+struct LaneSide {
+    std::vector<dj_join_rec> jrecs;
+    std::vector<uint64_t> joff;            // where each join's message starts in bytes
+    std::vector<uint8_t> bytes;
+    std::vector<Answer> jans;
+    std::vector<dj_fork_rec> frecs;
+    std::vector<Answer> fans;
+    std::vector<uint32_t> cut_f, cut_j;    // forks / joins staged when each later phase began
+    // low fingerprint halves of the joins of the current phase (open addressing, 0 = free): a fork that hits one
+    // starts a new phase.  A false hit (two ids with the same low half) only costs a phase.
+    std::vector<uint64_t> jset;
+    std::vector<uint32_t> jset_cells;      // the cells in use, so that clearing costs what was inserted, not the table
+    uint32_t jset_n = 0;
+
+    bool empty() const { return jrecs.empty() && frecs.empty(); }
+    void clear() {
+        jrecs.clear(); joff.clear(); bytes.clear(); jans.clear(); frecs.clear(); fans.clear(); cut_f.clear(); cut_j.clear();
+        clear_set();
+    }
+    void clear_set() {
+        for (uint32_t c : jset_cells) jset[c] = 0;
+        jset_cells.clear();
+        jset_n = 0;
+    }
+    bool set_has(uint64_t k) const {
+        if (!jset_n) return false;
+        const size_t m = jset.size() - 1;
+        for (size_t h = (k * 0x9E3779B97F4A7C15ull) >> 20 & m;; h = (h + 1) & m) {
+            if (jset[h] == k) return true;
+            if (jset[h] == 0) return false;
+        }
+    }
+    void set_add(uint64_t k) {
+        if (jset.size() < 2 * (size_t)(jset_n + 1)) {
+            std::vector<uint64_t> old;
+            old.swap(jset);
+            jset.assign(old.empty() ? 64 : old.size() * 2, 0ull);
+            jset_n = 0;
+            jset_cells.clear();
+            for (uint64_t v : old) if (v) set_add(v);
+        }
+        const size_t m = jset.size() - 1;
+        for (size_t h = (k * 0x9E3779B97F4A7C15ull) >> 20 & m;; h = (h + 1) & m) {
+            if (jset[h] == k) return;
+            if (jset[h] == 0) { jset[h] = k; jset_cells.push_back((uint32_t)h); ++jset_n; return; }
+        }
+    }
+};
+
+struct alignas(128) Lane {
+    std::mutex mu;
+    std::condition_variable cv_space;
+    LaneSide side[2];
+    int fill = 0;
 };
 
 uint64_t wall_clock_ms(void*) {
@@ -54,115 +113,222 @@ struct dj_batcher {
     dj_batcher_config cfg{};
     dj_config ecfg{};
     uint64_t pitch = 0;
-    Side side[2];
-    int fill = 0;                    // producers write side[fill]
-    bool first_set = false;
-    std::chrono::steady_clock::time_point first_arrival;
+    Lane lanes[LANES];
+    std::atomic<uint32_t> next_lane{0};
+    std::atomic<bool> sleeping{false};
+    // shared state (tasks, waiters, statistics, stop): off the staging path
     std::mutex mu;
-    std::condition_variable cv_work, cv_space, cv_done;
+    std::condition_variable cv_work, cv_done;
+    std::vector<Task> tasks;
     std::thread th;
     bool stop = false;
+    bool poked = false, lane_full = false;   // set by producers (under mu) when they wake the drain thread
     uint64_t (*clock_fn)(void*) = wall_clock_ms;
     void* clock_user = nullptr;
-    // device side
+    // pinned staging of one engine call, and the device side
+    dj_join_rec* h_jrecs = nullptr;
+    uint8_t* h_jpay = nullptr;
+    dj_fork_rec* h_frecs = nullptr;
+    std::vector<Answer> ans;
     dj_join_rec* d_jrecs = nullptr;
     uint8_t* d_jpay = nullptr;
     dj_fork_rec* d_frecs = nullptr;
     int32_t* d_status = nullptr;
-    int32_t* h_status = nullptr;     // pinned, 2 * max_batch (forks, joins)
+    int32_t* h_status = nullptr;     // pinned, max_batch
     dj_batcher_stats stats{};
     int fatal = 0;                   // first engine error seen by the drain thread; answers carry it as status
 };
 
 namespace {
 
+thread_local const dj_batcher* tl_owner = nullptr;
+thread_local int tl_lane = 0;
+
+Lane& my_lane(dj_batcher* b) {
+    if (tl_owner != b) {
+        tl_owner = b;
+        tl_lane = (int)(b->next_lane.fetch_add(1, std::memory_order_relaxed) % LANES);
+    }
+    return b->lanes[tl_lane];
+}
+
 void wait_cb(void* user, int32_t status) {
     // runs on the drain thread with the batcher's mutex NOT held; the waiter sleeps on cv_done
-    Waiter* w = static_cast<Waiter*>(user);
-    w->status = status;
+    static_cast<Waiter*>(user)->status = status;
 }
 
 bool hip_ok(hipError_t r) { return r == hipSuccess; }
 
-// one drain cycle on a closed side
-void apply(dj_batcher* b, Side& s, uint64_t (*clock_fn)(void*), void* clock_user) {
-    hipStream_t st = static_cast<hipStream_t>(dj_stream(b->e));
-    const uint64_t now = clock_fn(clock_user);
-    const uint32_t mb = b->cfg.max_batch;
-    int rc = DJ_OK;
-    if (s.nf && rc == DJ_OK) {
-        if (!hip_ok(hipMemcpyAsync(b->d_frecs, s.frecs, (size_t)s.nf * sizeof(dj_fork_rec), hipMemcpyHostToDevice, st))) rc = DJ_E_HIP;
-        if (rc == DJ_OK) rc = dj_fork_batch(b->e, s.nf, b->d_frecs, b->d_status);
-        if (rc == DJ_OK && !hip_ok(hipMemcpyAsync(b->h_status, b->d_status, (size_t)s.nf * 4, hipMemcpyDeviceToHost, st))) rc = DJ_E_HIP;
-    }
-    if (s.nj && rc == DJ_OK) {
-        if (!hip_ok(hipMemcpyAsync(b->d_jrecs, s.jrecs, (size_t)s.nj * sizeof(dj_join_rec), hipMemcpyHostToDevice, st))) rc = DJ_E_HIP;
-        if (rc == DJ_OK && !hip_ok(hipMemcpyAsync(b->d_jpay, s.jpay, (size_t)s.nj * b->pitch, hipMemcpyHostToDevice, st))) rc = DJ_E_HIP;
-        if (rc == DJ_OK) rc = dj_join_batch(b->e, s.nj, b->d_jrecs, b->d_jpay, b->pitch, now, b->d_status + mb);
-        if (rc == DJ_OK && !hip_ok(hipMemcpyAsync(b->h_status + mb, b->d_status + mb, (size_t)s.nj * 4, hipMemcpyDeviceToHost, st))) rc = DJ_E_HIP;
-    }
-    if (rc == DJ_OK && (s.nf || s.nj)) rc = dj_sync(b->e);
-    if (rc != DJ_OK && !b->fatal) b->fatal = rc;
-    // answers: forks first (they were applied first), then joins; an engine failure is reported as
-    // the (negative) error code in place of a status
-    for (uint32_t i = 0; i < s.nf; ++i) s.fans[i].cb(s.fans[i].user, rc == DJ_OK ? b->h_status[i] : rc);
-    for (uint32_t i = 0; i < s.nj; ++i) s.jans[i].cb(s.jans[i].user, rc == DJ_OK ? b->h_status[mb + i] : rc);
-    for (Task& t : s.tasks) {
-        const int r = t.fn(t.user, b->e, now);
-        t.w->status = r;
-    }
-    {
+// Wake the drain thread if it sleeps (called after a lane went from empty to non-empty, or when a lane is full).
+// The drain thread raises `sleeping` BEFORE it looks at the lanes (under their locks), so a producer that
+// staged after that look finds the flag raised; one that staged before it is found by the look.
+void poke(dj_batcher* b, bool full) {
+    if (b->sleeping.load(std::memory_order_seq_cst)) {
         std::lock_guard<std::mutex> g(b->mu);
-        if (s.nf || s.nj) {
-            ++b->stats.batches;
-            b->stats.forks += s.nf;
-            b->stats.joins += s.nj;
-            const uint64_t big = s.nf > s.nj ? s.nf : s.nj;
-            if (big > b->stats.largest_batch) b->stats.largest_batch = big;
-        }
-        b->stats.tasks += s.tasks.size();
-        // every waiter of this cycle (wait_cb users and tasks) may go now
-        for (uint32_t i = 0; i < s.nf; ++i)
-            if (s.fans[i].cb == wait_cb) static_cast<Waiter*>(s.fans[i].user)->done = true;
-        for (uint32_t i = 0; i < s.nj; ++i)
-            if (s.jans[i].cb == wait_cb) static_cast<Waiter*>(s.jans[i].user)->done = true;
-        for (Task& t : s.tasks) t.w->done = true;
-        s.nf = s.nj = 0;
-        s.tasks.clear();
+        b->poked = true;
+        if (full) b->lane_full = true;
+        b->cv_work.notify_one();
     }
-    b->cv_done.notify_all();
+}
+
+struct Window {
+    LaneSide* side[LANES];
+    int n = 0;
+    uint64_t forks = 0, joins = 0;
+    uint32_t phases = 1;
+};
+
+// rows [from, to) of one closed side's forks / joins in phase p
+void phase_range(const std::vector<uint32_t>& cuts, size_t total, uint32_t p, uint32_t* from, uint32_t* to) {
+    *from = p == 0 ? 0 : (p - 1 < cuts.size() ? cuts[p - 1] : (uint32_t)total);
+    *to = p < cuts.size() ? cuts[p] : (uint32_t)total;
+}
+
+void answer_all(dj_batcher* b, uint32_t n, int rc) {
+    for (uint32_t i = 0; i < n; ++i) b->ans[i].cb(b->ans[i].user, rc == DJ_OK ? b->h_status[i] : rc);
+}
+
+// one window: phases of (fork batch, join batch), each in engine calls of at most max_batch records
+void apply(dj_batcher* b, Window& w, uint64_t now, std::vector<Waiter*>& waiters) {
+    hipStream_t st = static_cast<hipStream_t>(dj_stream(b->e));
+    const uint32_t mb = b->cfg.max_batch;
+    int rc = b->fatal;
+    uint64_t largest = 0, calls = 0;
+    auto flush_forks = [&](uint32_t n) {
+        if (!n) return;
+        if (rc == DJ_OK && !hip_ok(hipMemcpyAsync(b->d_frecs, b->h_frecs, (size_t)n * sizeof(dj_fork_rec), hipMemcpyHostToDevice, st))) rc = DJ_E_HIP;
+        if (rc == DJ_OK) rc = dj_fork_batch(b->e, n, b->d_frecs, b->d_status);
+        if (rc == DJ_OK && !hip_ok(hipMemcpyAsync(b->h_status, b->d_status, (size_t)n * 4, hipMemcpyDeviceToHost, st))) rc = DJ_E_HIP;
+        if (rc == DJ_OK) rc = dj_sync(b->e);
+        answer_all(b, n, rc);
+        if (n > largest) largest = n;
+        ++calls;
+    };
+    auto flush_joins = [&](uint32_t n) {
+        if (!n) return;
+        if (rc == DJ_OK && !hip_ok(hipMemcpyAsync(b->d_jrecs, b->h_jrecs, (size_t)n * sizeof(dj_join_rec), hipMemcpyHostToDevice, st))) rc = DJ_E_HIP;
+        if (rc == DJ_OK && !hip_ok(hipMemcpyAsync(b->d_jpay, b->h_jpay, (size_t)n * b->pitch, hipMemcpyHostToDevice, st))) rc = DJ_E_HIP;
+        if (rc == DJ_OK) rc = dj_join_batch(b->e, n, b->d_jrecs, b->d_jpay, b->pitch, now, b->d_status);
+        if (rc == DJ_OK && !hip_ok(hipMemcpyAsync(b->h_status, b->d_status, (size_t)n * 4, hipMemcpyDeviceToHost, st))) rc = DJ_E_HIP;
+        if (rc == DJ_OK) rc = dj_sync(b->e);
+        answer_all(b, n, rc);
+        if (n > largest) largest = n;
+        ++calls;
+    };
+    for (uint32_t p = 0; p < w.phases; ++p) {
+        uint32_t n = 0;
+        for (int k = 0; k < w.n; ++k) {
+            LaneSide& s = *w.side[k];
+            uint32_t from, to;
+            phase_range(s.cut_f, s.frecs.size(), p, &from, &to);
+            for (uint32_t i = from; i < to; ++i) {
+                b->h_frecs[n] = s.frecs[i];
+                b->ans[n] = s.fans[i];
+                if (s.fans[i].cb == wait_cb) waiters.push_back(static_cast<Waiter*>(s.fans[i].user));
+                if (++n == mb) { flush_forks(n); n = 0; }
+            }
+        }
+        flush_forks(n);
+        n = 0;
+        for (int k = 0; k < w.n; ++k) {
+            LaneSide& s = *w.side[k];
+            uint32_t from, to;
+            phase_range(s.cut_j, s.jrecs.size(), p, &from, &to);
+            for (uint32_t i = from; i < to; ++i) {
+                b->h_jrecs[n] = s.jrecs[i];
+                if (s.jrecs[i].len) memcpy(b->h_jpay + (size_t)n * b->pitch, s.bytes.data() + s.joff[i], s.jrecs[i].len);
+                b->ans[n] = s.jans[i];
+                if (s.jans[i].cb == wait_cb) waiters.push_back(static_cast<Waiter*>(s.jans[i].user));
+                if (++n == mb) { flush_joins(n); n = 0; }
+            }
+        }
+        flush_joins(n);
+    }
+    if (rc != DJ_OK && !b->fatal) b->fatal = rc;
+    std::lock_guard<std::mutex> g(b->mu);
+    if (w.forks || w.joins) {
+        b->stats.batches += calls;
+        b->stats.forks += w.forks;
+        b->stats.joins += w.joins;
+        if (largest > b->stats.largest_batch) b->stats.largest_batch = largest;
+    }
 }
 
 void drain_loop(dj_batcher* b) {
     (void)hipSetDevice(b->ecfg.device);
-    std::unique_lock<std::mutex> lk(b->mu);
+    std::vector<Waiter*> waiters;
+    std::vector<Task> tasks;
     for (;;) {
-        Side* s = &b->side[b->fill];
-        b->cv_work.wait(lk, [&] { s = &b->side[b->fill]; return b->stop || s->nf || s->nj || !s->tasks.empty(); });
-        if (!(s->nf || s->nj || !s->tasks.empty())) break;      // stop requested and nothing queued
-        // linger for more requests, but never longer than max_wait_us after the first one; tasks do not linger
-        if (s->tasks.empty() && !b->stop && b->cfg.max_wait_us) {
-            const auto deadline = b->first_arrival + std::chrono::microseconds(b->cfg.max_wait_us);
-            b->cv_work.wait_until(lk, deadline, [&] {
-                return b->stop || s->nf >= b->cfg.max_batch || s->nj >= b->cfg.max_batch || !s->tasks.empty();
-            });
+        // ---- wait for work ----------------------------------------------------------------------------------
+        auto any_staged = [&] {
+            for (Lane& l : b->lanes) {
+                std::lock_guard<std::mutex> g(l.mu);
+                if (!l.side[l.fill].empty()) return true;
+            }
+            return false;
+        };
+        bool staged = any_staged();
+        {
+            std::unique_lock<std::mutex> lk(b->mu);
+            if (!staged && b->tasks.empty()) {
+                if (b->stop) return;                  // stop requested and nothing queued
+                b->sleeping.store(true, std::memory_order_seq_cst);
+                lk.unlock();
+                staged = any_staged();
+                lk.lock();
+                if (!staged) b->cv_work.wait_for(lk, std::chrono::milliseconds(20), [&] { return b->poked || !b->tasks.empty() || b->stop; });
+                b->sleeping.store(false, std::memory_order_seq_cst);
+                b->poked = b->lane_full = false;
+                continue;                             // look again
+            }
+            // linger for more requests, but never longer than max_wait_us after the window's first one was
+            // noticed; tasks do not linger.  A producer that finds its lane full ends the linger.
+            if (staged && b->tasks.empty() && !b->stop && b->cfg.max_wait_us) {
+                b->sleeping.store(true, std::memory_order_seq_cst);
+                b->cv_work.wait_for(lk, std::chrono::microseconds(b->cfg.max_wait_us), [&] { return b->lane_full || !b->tasks.empty() || b->stop; });
+                b->sleeping.store(false, std::memory_order_seq_cst);
+            }
+            b->poked = b->lane_full = false;
+            tasks.swap(b->tasks);
         }
-        const int cur = b->fill;
-        b->fill ^= 1;
-        b->first_set = false;
-        uint64_t (*const clock_fn)(void*) = b->clock_fn;     // as set under the mutex; called without it
-        void* const clock_user = b->clock_user;
-        lk.unlock();
-        b->cv_space.notify_all();
-        apply(b, b->side[cur], clock_fn, clock_user);
-        lk.lock();
-    }
-}
-
-void note_first(dj_batcher* b) {
-    if (!b->first_set) {
-        b->first_set = true;
-        b->first_arrival = std::chrono::steady_clock::now();
+        // ---- close the window: every lane's filling side at once ----------------------------------------------
+        Window w;
+        for (Lane& l : b->lanes) {
+            std::unique_lock<std::mutex> g(l.mu);
+            LaneSide& s = l.side[l.fill];
+            if (s.empty()) continue;
+            l.fill ^= 1;
+            g.unlock();
+            l.cv_space.notify_all();
+            w.side[w.n++] = &s;
+            w.forks += s.frecs.size();
+            w.joins += s.jrecs.size();
+            const uint32_t ph = (uint32_t)s.cut_f.size() + 1;
+            if (ph > w.phases) w.phases = ph;
+        }
+        uint64_t (*clock_fn)(void*);
+        void* clock_user;
+        {
+            std::lock_guard<std::mutex> g(b->mu);
+            clock_fn = b->clock_fn;
+            clock_user = b->clock_user;
+        }
+        const uint64_t now = clock_fn(clock_user);
+        waiters.clear();
+        if (w.n) apply(b, w, now, waiters);
+        for (int k = 0; k < w.n; ++k) {
+            // the closed side is the lane's spare now; nobody touches it until the next swap, which this thread does
+            w.side[k]->clear();
+        }
+        for (Task& t : tasks) t.w->status = t.fn(t.user, b->e, now);
+        if (!waiters.empty() || !tasks.empty()) {
+            std::lock_guard<std::mutex> g(b->mu);
+            for (Waiter* x : waiters) x->done = true;
+            for (Task& t : tasks) t.w->done = true;
+            b->stats.tasks += tasks.size();
+        }
+        if (!waiters.empty() || !tasks.empty()) b->cv_done.notify_all();
+        tasks.clear();
     }
 }
 
@@ -182,18 +348,15 @@ extern "C" int dj_batcher_create(dj_engine* e, const dj_batcher_config* cfg, dj_
     b->pitch = ((uint64_t)(cfg->max_message ? cfg->max_message : 1) + 15) / 16 * 16;
     const size_t mb = cfg->max_batch;
     bool ok = hip_ok(hipSetDevice(ec.device));
-    for (Side& s : b->side) {
-        ok = ok && hip_ok(hipHostMalloc((void**)&s.jrecs, mb * sizeof(dj_join_rec), hipHostMallocDefault));
-        ok = ok && hip_ok(hipHostMalloc((void**)&s.jpay, mb * b->pitch, hipHostMallocDefault));
-        ok = ok && hip_ok(hipHostMalloc((void**)&s.frecs, mb * sizeof(dj_fork_rec), hipHostMallocDefault));
-        s.jans.resize(mb);
-        s.fans.resize(mb);
-    }
+    ok = ok && hip_ok(hipHostMalloc((void**)&b->h_jrecs, mb * sizeof(dj_join_rec), hipHostMallocDefault));
+    ok = ok && hip_ok(hipHostMalloc((void**)&b->h_jpay, mb * b->pitch, hipHostMallocDefault));
+    ok = ok && hip_ok(hipHostMalloc((void**)&b->h_frecs, mb * sizeof(dj_fork_rec), hipHostMallocDefault));
+    b->ans.resize(mb);
     ok = ok && hip_ok(hipMalloc((void**)&b->d_jrecs, mb * sizeof(dj_join_rec)));
     ok = ok && hip_ok(hipMalloc((void**)&b->d_jpay, mb * b->pitch));
     ok = ok && hip_ok(hipMalloc((void**)&b->d_frecs, mb * sizeof(dj_fork_rec)));
-    ok = ok && hip_ok(hipMalloc((void**)&b->d_status, 2 * mb * 4));
-    ok = ok && hip_ok(hipHostMalloc((void**)&b->h_status, 2 * mb * 4, hipHostMallocDefault));
+    ok = ok && hip_ok(hipMalloc((void**)&b->d_status, mb * 4));
+    ok = ok && hip_ok(hipHostMalloc((void**)&b->h_status, mb * 4, hipHostMallocDefault));
     if (!ok) {
         dj_batcher_destroy(b);
         return DJ_E_NOMEM;
@@ -214,11 +377,9 @@ extern "C" void dj_batcher_destroy(dj_batcher* b) {
         b->th.join();
     }
     (void)hipSetDevice(b->ecfg.device);
-    for (Side& s : b->side) {
-        if (s.jrecs) (void)hipHostFree(s.jrecs);
-        if (s.jpay) (void)hipHostFree(s.jpay);
-        if (s.frecs) (void)hipHostFree(s.frecs);
-    }
+    if (b->h_jrecs) (void)hipHostFree(b->h_jrecs);
+    if (b->h_jpay) (void)hipHostFree(b->h_jpay);
+    if (b->h_frecs) (void)hipHostFree(b->h_frecs);
     if (b->d_jrecs) (void)hipFree(b->d_jrecs);
     if (b->d_jpay) (void)hipFree(b->d_jpay);
     if (b->d_frecs) (void)hipFree(b->d_frecs);
@@ -235,6 +396,11 @@ extern "C" int dj_batcher_set_clock(dj_batcher* b, uint64_t (*now_ms)(void*), vo
     return DJ_OK;
 }
 
+static bool stopping(dj_batcher* b) {
+    std::lock_guard<std::mutex> g(b->mu);
+    return b->stop;
+}
+
 extern "C" int dj_batcher_join(dj_batcher* b, const dj_join_rec* rec, const void* message, dj_status_cb cb, void* user) {
     if (!b || !rec || !cb || (rec->len && !message)) return DJ_E_INVALID;
     if (rec->len > b->cfg.max_message) {          // would not fit the staging row; the engine's answer for it
@@ -245,34 +411,50 @@ extern "C" int dj_batcher_join(dj_batcher* b, const dj_join_rec* rec, const void
         }
         return DJ_OK;
     }
-    std::unique_lock<std::mutex> lk(b->mu);
-    if (b->stop) return DJ_E_INVALID;
-    b->cv_space.wait(lk, [&] { return b->side[b->fill].nj < b->cfg.max_batch; });
-    Side& s = b->side[b->fill];
-    const uint32_t i = s.nj++;
-    s.jrecs[i] = *rec;
-    if (rec->len) memcpy(s.jpay + (size_t)i * b->pitch, message, rec->len);
-    s.jans[i] = Answer{cb, user};
-    note_first(b);
-    const bool wake = i == 0 || s.nj >= b->cfg.max_batch;
+    Lane& l = my_lane(b);
+    std::unique_lock<std::mutex> lk(l.mu);
+    while (l.side[l.fill].jrecs.size() >= b->cfg.max_batch) {
+        lk.unlock();
+        if (stopping(b)) return DJ_E_INVALID;
+        poke(b, true);                            // a full lane ends the drain thread's linger
+        lk.lock();
+        l.cv_space.wait_for(lk, std::chrono::milliseconds(1), [&] { return l.side[l.fill].jrecs.size() < b->cfg.max_batch; });
+    }
+    LaneSide& s = l.side[l.fill];
+    const bool was_empty = s.empty();
+    s.jrecs.push_back(*rec);
+    s.joff.push_back(s.bytes.size());
+    if (rec->len) s.bytes.insert(s.bytes.end(), static_cast<const uint8_t*>(message), static_cast<const uint8_t*>(message) + rec->len);
+    s.jans.push_back(Answer{cb, user});
+    s.set_add(rec->fp_lo);
     lk.unlock();
-    if (wake) b->cv_work.notify_one();
+    if (was_empty) poke(b, false);
     return DJ_OK;
 }
 
 extern "C" int dj_batcher_fork(dj_batcher* b, const dj_fork_rec* rec, dj_status_cb cb, void* user) {
     if (!b || !rec || !cb) return DJ_E_INVALID;
-    std::unique_lock<std::mutex> lk(b->mu);
-    if (b->stop) return DJ_E_INVALID;
-    b->cv_space.wait(lk, [&] { return b->side[b->fill].nf < b->cfg.max_batch; });
-    Side& s = b->side[b->fill];
-    const uint32_t i = s.nf++;
-    s.frecs[i] = *rec;
-    s.fans[i] = Answer{cb, user};
-    note_first(b);
-    const bool wake = i == 0 || s.nf >= b->cfg.max_batch;
+    Lane& l = my_lane(b);
+    std::unique_lock<std::mutex> lk(l.mu);
+    while (l.side[l.fill].frecs.size() >= b->cfg.max_batch) {
+        lk.unlock();
+        if (stopping(b)) return DJ_E_INVALID;
+        poke(b, true);
+        lk.lock();
+        l.cv_space.wait_for(lk, std::chrono::milliseconds(1), [&] { return l.side[l.fill].frecs.size() < b->cfg.max_batch; });
+    }
+    LaneSide& s = l.side[l.fill];
+    const bool was_empty = s.empty();
+    if (s.set_has(rec->fp_lo)) {
+        // a join of this barrier waits in the current phase: the fork must not overtake it
+        s.cut_f.push_back((uint32_t)s.frecs.size());
+        s.cut_j.push_back((uint32_t)s.jrecs.size());
+        s.clear_set();
+    }
+    s.frecs.push_back(*rec);
+    s.fans.push_back(Answer{cb, user});
     lk.unlock();
-    if (wake) b->cv_work.notify_one();
+    if (was_empty) poke(b, false);
     return DJ_OK;
 }
 
@@ -303,8 +485,7 @@ extern "C" int dj_batcher_run(dj_batcher* b, int (*fn)(void*, dj_engine*, uint64
     {
         std::unique_lock<std::mutex> lk(b->mu);
         if (b->stop) return DJ_E_INVALID;
-        b->side[b->fill].tasks.push_back(Task{fn, user, &w});
-        note_first(b);
+        b->tasks.push_back(Task{fn, user, &w});
     }
     b->cv_work.notify_one();
     int32_t r = 0;

@@ -32,6 +32,17 @@ DEFAULT_ENV = {
 }
 
 
+def clojure_count(s):
+    """(count s) of a java.lang.String: UTF-16 code units (a character beyond the BMP counts as two)."""
+    return len(s.encode("utf-16-le")) // 2
+
+
+def engine_message_bytes(env=DEFAULT_ENV):
+    """dj_config.max_message_bytes for an engine behind these limits: the reference limits a message's
+    CHARACTERS (store.clj:24-26), the engine stores UTF-8 bytes, at most three per UTF-16 code unit."""
+    return min(3 * env["join-message-len-max"], 1 << 20)
+
+
 def _is_int(v):
     return isinstance(v, int) and not isinstance(v, bool)
 
@@ -91,7 +102,7 @@ def validate_join(req, env=DEFAULT_ENV):
     if not _is_int(p) or p < 0:
         return "position must be a non-negative integer"
     m = req.get("message")
-    if not isinstance(m, str) or len(m) > env["join-message-len-max"]:
+    if not isinstance(m, str) or clojure_count(m) > env["join-message-len-max"]:           # (count %), store.clj:25
         return f"Message length cannot exceed {env['join-message-len-max']}"
     if "max-wait" in req:
         mw = req["max-wait"]

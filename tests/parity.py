@@ -34,8 +34,9 @@ def payload_bytes(barrier, pos, version, pitch):
 
 
 class ParityDriver:
-    def __init__(self, engine, oracle, ids):
+    def __init__(self, engine, oracle, ids, oracle_caps=None):
         self.e, self.o = engine, oracle
+        self.oracle_caps = oracle_caps or {}      # cap_conts / cap_positions of the oracle's sweep buffers (rows of its whole-message width)
         self.ids = list(ids)
         self.fps = capi.fingerprint_many(self.ids)
         self.by_fp = {(int(a), int(b)): k for k, (a, b) in enumerate(self.fps)}
@@ -99,7 +100,7 @@ class ParityDriver:
     def sweep(self, now):
         conts, lens, mws, pay, more = self.e.sweep(now)
         assert not more, "engine sweep hit its host caps in a parity test"
-        oc, ol, om, op_ = self.o.sweep(now)
+        oc, ol, om, op_ = self.o.sweep(now, **self.oracle_caps)
         got, want = self._canon_engine(conts, lens, mws, pay), self._canon_oracle(oc, ol, om, op_)
         assert got.keys() == want.keys(), f"popped sets differ: only engine {sorted(got.keys() - want.keys())[:10]} only oracle {sorted(want.keys() - got.keys())[:10]}"
         for k in want:

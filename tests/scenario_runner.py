@@ -7,7 +7,7 @@ known answers.
 import json
 import os
 
-from distributed_join_amd import capi
+from distributed_join_amd import capi, edn
 from distributed_join_amd.core import ForkJoinService, PublishError
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -26,11 +26,17 @@ class FakeDestination:
 
     def __init__(self):
         self.requests = []
+        self.bodies = []
         self.hook = None
 
-    def post(self, url, body):
+    def post(self, url, body, content_type):
+        # what the destination receives: EDN bytes (publish.clj:9-11); it reads them like any EDN consumer would
+        assert isinstance(body, bytes) and content_type == "application/edn"
+        barrier_id, messages = edn.decode(body)
+        assert edn.encode(barrier_id, messages) == body
+        self.bodies.append(body)
         failed = url is None or "/bad/" in url
-        self.requests.append({"url": url, "barrier-id": body["barrier-id"], "messages": body["messages"], "failed": failed})
+        self.requests.append({"url": url, "barrier-id": barrier_id, "messages": messages, "failed": failed})
         if self.hook:
             self.hook()
         if failed:
@@ -76,6 +82,7 @@ def run_scenario(sc, t0, make_store):
                         assert j["position"] == p and j["barrier-id"] == step["id"], ctx
         elif kind == "process_publish":
             dest.requests.clear()
+            dest.bodies.clear()
             nested = step.get("during_post")
 
             def hook():
@@ -94,6 +101,10 @@ def run_scenario(sc, t0, make_store):
                 key = lambda r: r["barrier-id"]
                 want = sorted(({"failed": False, **p} for p in exp["posts"]), key=key)
                 assert sorted(dest.requests, key=key) == want, f"{ctx}: got {dest.requests}"
+                # and the bytes on the wire, for the scenarios' plain messages: "x" prints as itself
+                assert sorted(dest.bodies) == sorted(
+                    ('{:barrier-id "%s", :messages (%s)}' % (p["barrier-id"], " ".join(
+                        "nil" if m is None else '"%s"' % m for m in p["messages"]))).encode() for p in exp["posts"]), ctx
             if "errors" in exp:
                 assert sum(isinstance(r, Exception) for r in res) == exp["errors"], f"{ctx}: got {res}"
             if "illegal_state" in exp:

@@ -132,3 +132,40 @@ def test_long_messages_through_the_batcher():
     assert bytes(pay[0][:5]) == b"short" and bytes(pay[1][:3000]) == long_msg
     b.close()
     e.close()
+
+
+def test_requests_of_one_thread_keep_their_order_inside_a_window():
+    """One thread stages, without waiting for any answer: join (no such barrier yet), fork, two joins, a re-fork
+    of the same id with another count, one join.  All five land in one window (the linger is long); the engine
+    applies forks and joins as separate batches, so the window must be cut where a fork follows a join of its
+    barrier: the answers and the final state are those of the requests taken one by one."""
+    from distributed_join_amd.batcher import Batcher
+    from distributed_join_amd.engine import Engine
+    e = Engine(capacity_barriers=64, arena_bytes=1 << 20, max_count=8, payload_stride=64, max_batch=256)
+    b = Batcher(e, max_batch=64, max_wait_us=200_000)
+    b.set_clock(lambda: T0 + 5)
+    fp = capi.fingerprint("order~1")
+    other = capi.fingerprint("order~2")
+    got = []
+    try:
+        b.join_async(fp, 0, b"early", lambda st: got.append(("j0", st)))
+        b.fork_async(fp, 2, T0 + 60_000, lambda st: got.append(("f1", st)))
+        b.fork_async(other, 1, T0 + 60_000, lambda st: got.append(("fo", st)))
+        b.join_async(fp, 0, b"a", lambda st: got.append(("j1", st)))
+        b.join_async(fp, 1, b"b", lambda st: got.append(("j2", st)))
+        b.fork_async(fp, 3, T0 + 60_000, lambda st: got.append(("f2", st)))
+        b.join_async(fp, 2, b"c", lambda st: got.append(("j3", st)))
+        b.join_async(other, 0, b"o", lambda st: got.append(("jo", st)))
+        b.run(lambda now: 0)                       # returns after everything staged before it was applied
+        ans = dict(got)
+        assert ans == {"j0": capi.DJ_JOIN_NOT_FOUND, "f1": capi.DJ_FORK_CREATED, "fo": capi.DJ_FORK_CREATED,
+                       "j1": capi.DJ_JOIN_WAITING, "j2": capi.DJ_JOIN_COMPLETE, "f2": capi.DJ_FORK_CREATED,
+                       "j3": capi.DJ_JOIN_WAITING, "jo": capi.DJ_JOIN_COMPLETE}, ans
+        # per kind, answers come in staging order
+        assert [k for k, _ in got if k[0] == "j" and k != "jo"] == ["j0", "j1", "j2", "j3"]
+        meta, lens, _, pay = e.snapshot_one(*fp)
+        assert int(meta["count"]) == 3 and lens.tolist() == [capi.DJ_NIL, capi.DJ_NIL, 1] and bytes(pay[2, :1]) == b"c"
+        assert b.stats()["batches"] >= 5           # three phases: join | fork + joins | fork + join
+    finally:
+        b.close()
+        e.close()

@@ -341,3 +341,48 @@ def test_messages_longer_than_a_row(oracle_lib, tmp_path, hot_mode):
     assert s["live"] == 0
     assert s["arena_units_free"] == s["arena_units_used"] - 1, s       # unit 0 is reserved
     d.e.close()
+
+
+def test_messages_of_the_reference_limit(oracle_lib):
+    """The reference's production limit is 262144 characters per message (config/prod/config.edn:38,
+    store.clj:24-26), i.e. up to 786432 UTF-8 bytes: an engine configured for it takes messages of exactly
+    262144 and 786432 bytes (and every size class between), overwrites them by shorter and longer ones, hands
+    them back byte for byte, and gives the blocks back when the barriers go."""
+    from distributed_join_amd.store import engine_message_bytes
+    rng = np.random.default_rng(262144)
+    M = engine_message_bytes()
+    assert M == 786432
+    nb, stride = 6, 256
+    ids = [f"big{b}~t" for b in range(nb)]
+    counts = np.array([1, 2, 3, 2, 1, 2])
+    e, o, d = make_pair(oracle_lib, ids, stride, max_count=8, capacity=64, arena=96 << 20, max_message=M, max_batch=64)
+    d.oracle_caps = dict(cap_conts=16, cap_positions=64)      # the oracle's sweep rows are M bytes wide
+    try:
+        now = T0
+        d.fork(np.arange(nb), counts, np.full(nb, now + 60_000))
+        pitch = M + 16
+        sizes = [262144, M, 262145, 65, 256, 257, 100_000, 524288, 0, M - 1]
+        for rnd in range(3):
+            now += 7
+            jb = rng.integers(0, nb, len(sizes))
+            pos = (rng.random(len(sizes)) * counts[jb]).astype(np.int64)
+            ln = np.array(sizes if rnd != 1 else sizes[::-1])
+            if rnd == 2:
+                ln[3] = M + 1                       # one byte too long: refused, the position keeps what it had
+            pay = payload_bytes(jb, pos, np.full(len(sizes), rnd) + np.arange(len(sizes)), pitch)
+            st = d.join(jb, pos, ln, np.zeros(len(sizes), np.int64), pay, now)
+            assert (st[ln > M] == capi.DJ_JOIN_TOO_LONG).all()
+            d.check_all_snapshots()
+        # fill what is missing with long messages, fire everything
+        now += 7
+        bb = np.repeat(np.arange(nb), counts)
+        pp = np.concatenate([np.arange(c) for c in counts])
+        ln = rng.integers(262144, M + 1, len(bb))
+        d.join(bb, pp, ln, np.zeros(len(bb), np.int64), payload_bytes(bb, pp, np.full(len(bb), 99), pitch), now)
+        ec, oc = d.sweep(now)
+        assert len(ec) == nb
+        assert set(d.ack(ec, oc, lambda k: True, now).values()) == {capi.DJ_ACK_DONE}
+        s = e.stats()
+        assert s["live"] == 0 and s["arena_units_free"] == s["arena_units_used"] - 1, s
+    finally:
+        e.close()

@@ -119,3 +119,18 @@ def test_max_wait_limits(svc):
     assert svc.join({**j, "max-wait": ENV["join-max-wait"] - 1})[0] == 202
     assert svc.join({**j, "max-wait": ENV["join-max-wait"]})[0] == 400
     assert svc.join({**j, "max-wait": 0})[0] == 400
+
+
+def test_message_limit_counts_characters_like_the_reference():
+    """store.clj:24-26 limits (count message): UTF-16 code units of the String, not bytes.  A message of exactly
+    the limit in three-byte characters (786432 UTF-8 bytes) is legal; one character more is not; a character
+    beyond the BMP counts as two."""
+    from distributed_join_amd.store import DEFAULT_ENV, clojure_count, engine_message_bytes, validate_join
+    n = DEFAULT_ENV["join-message-len-max"]
+    ok = {"barrier-id": "a~b", "position": 0, "message": "雪" * n}
+    assert len(ok["message"].encode()) == 3 * n == engine_message_bytes()
+    assert validate_join(ok) is None
+    assert validate_join({**ok, "message": "雪" * (n + 1)}) is not None
+    assert clojure_count("a😀") == 3
+    assert validate_join({**ok, "message": "😀" * (n // 2)}) is None
+    assert validate_join({**ok, "message": "😀" * (n // 2) + "a"}) is not None
