@@ -5,6 +5,8 @@
 // before a kernel is launched, so that a kernel never sees a shape it was not written for.
 #include <hip/hip_runtime.h>
 
+#include <unistd.h>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -846,21 +848,46 @@ extern "C" int dj_get_stats(dj_engine* e, dj_stats* h_stats) {
 // ---- durability -----------------------------------------------------------------------------
 namespace {
 struct CkptHeader {
-    char magic[8];               // "DJCKPT4\0"
+    char magic[8];               // "DJCKPT5\0"
     uint64_t slots, arena_units_used, arena_units_total;
     uint32_t stride, max_count;
     uint32_t ring_n[NUM_CLASSES];    // free slabs per class, stored head-first after the arena
     uint32_t oring_n[OVF_CLASSES];   // free long-message blocks per class, after the slab lists
     uint32_t max_message;
     uint64_t used_upper;
+    uint64_t payload_bytes;          // everything behind the header
+    uint64_t checksum;               // of those bytes (fnv-1a over 64-bit words, tail bytes zero-extended)
 };
 const size_t CKPT_CHUNK = 64u << 20;
 
-int dev_to_file(dj_engine* e, FILE* f, const void* dev, size_t bytes, void* stage) {
+struct Fnv {       // over the byte stream, whatever pieces it arrives in
+    uint64_t h = 0xCBF29CE484222325ull, bytes = 0;
+    uint8_t pend[8];
+    size_t npend = 0;
+    void word(const uint8_t* b) { uint64_t w; memcpy(&w, b, 8); h = (h ^ w) * 0x100000001B3ull; }
+    void add(const void* p, size_t n) {
+        const uint8_t* b = static_cast<const uint8_t*>(p);
+        bytes += n;
+        while (npend && n) { pend[npend++] = *b++; --n; if (npend == 8) { word(pend); npend = 0; } }
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) word(b + i);
+        for (; i < n; ++i) pend[npend++] = b[i];
+    }
+    uint64_t value() {
+        uint8_t last[8] = {0};
+        memcpy(last, pend, npend);
+        uint64_t v = h;
+        if (npend) { uint64_t w; memcpy(&w, last, 8); v = (v ^ w) * 0x100000001B3ull; }
+        return v ^ bytes;
+    }
+};
+
+int dev_to_file(dj_engine* e, FILE* f, const void* dev, size_t bytes, void* stage, Fnv* sum) {
     const uint8_t* p = static_cast<const uint8_t*>(dev);
     for (size_t off = 0; off < bytes; off += CKPT_CHUNK) {
-        const size_t m = bytes - off < CKPT_CHUNK ? bytes - off : CKPT_CHUNK;
+        const size_t m = bytes - off < CKPT_CHUNK ? bytes - off : CKPT_CHUNK;      // chunks are multiples of 8 bytes but the last
         HIP_TRY(e, hipMemcpy(stage, p + off, m, hipMemcpyDeviceToHost));
+        sum->add(stage, m);
         if (fwrite(stage, 1, m, f) != m) return fail(e, DJ_E_INVALID, "checkpoint: short write");
     }
     return DJ_OK;
@@ -886,7 +913,7 @@ extern "C" int dj_checkpoint_save(dj_engine* e, const char* path) {
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     CkptHeader h;
     memset(&h, 0, sizeof h);
-    memcpy(h.magic, "DJCKPT4", 8);
+    memcpy(h.magic, "DJCKPT5", 8);
     h.slots = e->t.mask + 1;
     h.arena_units_total = e->t.arena_units;
     h.stride = e->t.stride;
@@ -904,29 +931,41 @@ extern "C" int dj_checkpoint_save(dj_engine* e, const char* path) {
     HIP_TRY(e, hipMemcpy(ohead, e->t.oring_head, sizeof ohead, hipMemcpyDeviceToHost));
     HIP_TRY(e, hipMemcpy(otail, e->t.oring_tail, sizeof otail, hipMemcpyDeviceToHost));
     for (uint32_t k = 0; k < OVF_CLASSES; ++k) h.oring_n[k] = otail[k] - ohead[k];
-    FILE* f = fopen(path, "wb");
-    if (!f) return fail(e, DJ_E_INVALID, "checkpoint: cannot open %s for writing", path);
+    // written beside the target and renamed over it once complete and on disk: a crash in the middle of a
+    // periodic snapshot leaves the previous checkpoint as it was
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return fail(e, DJ_E_INVALID, "checkpoint: cannot open %s for writing", tmp.c_str());
     void* stage = malloc(CKPT_CHUNK);
-    if (!stage) { fclose(f); return fail(e, DJ_E_NOMEM, "checkpoint: no staging memory"); }
+    if (!stage) { fclose(f); remove(tmp.c_str()); return fail(e, DJ_E_NOMEM, "checkpoint: no staging memory"); }
+    Fnv sum;
     rc = fwrite(&h, sizeof h, 1, f) == 1 ? DJ_OK : fail(e, DJ_E_INVALID, "checkpoint: short write");
-    if (rc == DJ_OK) rc = dev_to_file(e, f, e->t.slots, h.slots * sizeof(Slot), stage);
-    if (rc == DJ_OK) rc = dev_to_file(e, f, e->t.q, h.slots * 8, stage);
-    if (rc == DJ_OK) rc = dev_to_file(e, f, e->t.arena, h.arena_units_used * 64, stage);
+    if (rc == DJ_OK) rc = dev_to_file(e, f, e->t.slots, h.slots * sizeof(Slot), stage, &sum);
+    if (rc == DJ_OK) rc = dev_to_file(e, f, e->t.q, h.slots * 8, stage, &sum);
+    if (rc == DJ_OK) rc = dev_to_file(e, f, e->t.arena, h.arena_units_used * 64, stage, &sum);
     for (uint32_t k = 0; k < NUM_CLASSES && rc == DJ_OK; ++k) {
         // the ring's live window [head, tail) may wrap: two pieces, head-first
         const uint32_t cap = e->t.ring_cap[k], n = h.ring_n[k], at = head[k] & (cap - 1);
         const uint32_t first = n < cap - at ? n : cap - at;
-        rc = dev_to_file(e, f, e->t.ring[k] + at, (size_t)first * 4, stage);
-        if (rc == DJ_OK) rc = dev_to_file(e, f, e->t.ring[k], (size_t)(n - first) * 4, stage);
+        rc = dev_to_file(e, f, e->t.ring[k] + at, (size_t)first * 4, stage, &sum);
+        if (rc == DJ_OK) rc = dev_to_file(e, f, e->t.ring[k], (size_t)(n - first) * 4, stage, &sum);
     }
     for (uint32_t k = 0; k < OVF_CLASSES && rc == DJ_OK; ++k) {
         const uint32_t cap = e->t.oring_cap[k], n = h.oring_n[k], at = ohead[k] & (cap - 1);
         const uint32_t first = n < cap - at ? n : cap - at;
-        rc = dev_to_file(e, f, e->t.oring[k] + at, (size_t)first * 4, stage);
-        if (rc == DJ_OK) rc = dev_to_file(e, f, e->t.oring[k], (size_t)(n - first) * 4, stage);
+        rc = dev_to_file(e, f, e->t.oring[k] + at, (size_t)first * 4, stage, &sum);
+        if (rc == DJ_OK) rc = dev_to_file(e, f, e->t.oring[k], (size_t)(n - first) * 4, stage, &sum);
     }
     free(stage);
+    if (rc == DJ_OK) {          // the header again, now with the size and checksum of what follows it
+        h.payload_bytes = sum.bytes;
+        h.checksum = sum.value();
+        if (fseek(f, 0, SEEK_SET) != 0 || fwrite(&h, sizeof h, 1, f) != 1) rc = fail(e, DJ_E_INVALID, "checkpoint: short write");
+    }
+    if (rc == DJ_OK && (fflush(f) != 0 || fsync(fileno(f)) != 0)) rc = fail(e, DJ_E_INVALID, "checkpoint: flush to disk failed");
     if (fclose(f) != 0 && rc == DJ_OK) rc = fail(e, DJ_E_INVALID, "checkpoint: close failed");
+    if (rc == DJ_OK && rename(tmp.c_str(), path) != 0) rc = fail(e, DJ_E_INVALID, "checkpoint: cannot rename %s to %s", tmp.c_str(), path);
+    if (rc != DJ_OK) remove(tmp.c_str());
     return rc;
 }
 
@@ -940,7 +979,7 @@ extern "C" int dj_checkpoint_load(dj_engine* e, const char* path) {
     FILE* f = fopen(path, "rb");
     if (!f) return fail(e, DJ_E_INVALID, "checkpoint: cannot open %s", path);
     CkptHeader h;
-    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "DJCKPT4", 8) != 0) {
+    if (fread(&h, sizeof h, 1, f) != 1 || memcmp(h.magic, "DJCKPT5", 8) != 0) {
         fclose(f);
         return fail(e, DJ_E_INVALID, "checkpoint: %s is not a checkpoint file", path);
     }
@@ -964,6 +1003,36 @@ extern "C" int dj_checkpoint_load(dj_engine* e, const char* path) {
         }
     void* stage = malloc(CKPT_CHUNK);
     if (!stage) { fclose(f); return fail(e, DJ_E_NOMEM, "checkpoint: no staging memory"); }
+    {   // first pass, nothing on the device is touched: the file must be whole (size, checksum) and its free
+        // lists must name units inside the saved arena
+        uint64_t want = h.slots * (sizeof(Slot) + 8) + h.arena_units_used * 64;
+        for (uint32_t k = 0; k < NUM_CLASSES; ++k) want += (uint64_t)h.ring_n[k] * 4;
+        for (uint32_t k = 0; k < OVF_CLASSES; ++k) want += (uint64_t)h.oring_n[k] * 4;
+        Fnv sum;
+        const uint64_t lists_at = h.slots * (sizeof(Slot) + 8) + h.arena_units_used * 64;
+        bool lists_ok = true;
+        for (uint64_t off = 0; h.payload_bytes == want && off < want;) {
+            const size_t m = want - off < CKPT_CHUNK ? (size_t)(want - off) : CKPT_CHUNK;
+            if (fread(stage, 1, m, f) != m) break;
+            sum.add(stage, m);
+            // entries of the free lists (4 bytes each, 4-byte aligned in the stream: everything before them is a multiple of 8)
+            const uint64_t from = off > lists_at ? off : lists_at;
+            for (uint64_t p = from; p + 4 <= off + m; p += 4) {
+                uint32_t unit;
+                memcpy(&unit, static_cast<uint8_t*>(stage) + (p - off), 4);
+                if (unit == 0 || unit >= h.arena_units_used) lists_ok = false;
+            }
+            off += m;
+        }
+        const bool whole = h.payload_bytes == want && sum.bytes == want && sum.value() == h.checksum && fgetc(f) == EOF;
+        if (!whole || !lists_ok) {
+            free(stage);
+            fclose(f);
+            return fail(e, DJ_E_INVALID, "checkpoint: %s is %s; the engine's state was left as it was", path,
+                        whole ? "inconsistent (a free list names a unit outside the saved arena)" : "truncated or damaged (size or checksum mismatch)");
+        }
+        if (fseek(f, (long)sizeof h, SEEK_SET) != 0) { free(stage); fclose(f); return fail(e, DJ_E_INVALID, "checkpoint: seek failed"); }
+    }
     rc = file_to_dev(e, f, e->t.slots, h.slots * sizeof(Slot), stage);
     if (rc == DJ_OK) rc = file_to_dev(e, f, e->t.q, h.slots * 8, stage);
     if (rc == DJ_OK) rc = file_to_dev(e, f, e->t.arena, h.arena_units_used * 64, stage);

@@ -1319,7 +1319,10 @@ __global__ void __launch_bounds__(ACK_BLOCK) ack_kernel(Table t, uint32_t n_max,
     dj_cont c = {};
     const bool live = i < n;
     if (live) c = conts[i];
-    if (live && !(c.flags & CONT_VOID)) {
+    // a row that no sweep of this engine can have written (a snapshot with metadata whose :count is outside
+    // 1..max_count): answered 0 like a void row, nothing changes
+    const bool sane = (c.flags & DJ_CONT_NO_METADATA) || (c.count >= 1 && c.count <= t.max_count);
+    if (live && !(c.flags & CONT_VOID) && sane) {
         const bool published = ok == nullptr || ok[i] != 0;
         const bool has_md = !(c.flags & DJ_CONT_NO_METADATA);
         rp = retry_from_api(c.retry_publish);

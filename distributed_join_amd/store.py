@@ -138,10 +138,19 @@ class EngineStore:
         self.e = engine
         self.names = {}          # (fp_lo, fp_hi) -> barrier-id
 
-    def _fp(self, barrier_id):
+    def _fp(self, barrier_id, register=False):
+        """Fingerprint of an id.  Only forks (and explicit queue entries) register the name: joins and status
+        lookups of ids nobody forked must not grow the table, and a barrier's name goes when the barrier does."""
         fp = capi.fingerprint(barrier_id)
-        self.names.setdefault(fp, barrier_id)
+        if register:
+            self.names[fp] = barrier_id
         return fp
+
+    def _forget(self, conts, statuses):
+        gone = (capi.DJ_ACK_DONE, capi.DJ_ACK_DROPPED_EXHAUSTED, capi.DJ_ACK_DONE_NO_METADATA)
+        for c, st in zip(conts, statuses):
+            if int(st) in gone:
+                self.names.pop(capi.fingerprint(c.barrier_id), None)
 
     def _name(self, lo, hi):
         return self.names.get((int(lo), int(hi)), f"<unknown {int(lo):016x}{int(hi):016x}>")
@@ -150,7 +159,7 @@ class EngineStore:
     def fork_many(self, ids, counts, deadlines):
         recs = np.zeros(len(ids), dtype=capi.FORK_REC)
         for k, i in enumerate(ids):
-            recs[k]["fp_lo"], recs[k]["fp_hi"] = self._fp(i)
+            recs[k]["fp_lo"], recs[k]["fp_hi"] = self._fp(i, register=True)
         recs["count"] = np.asarray(counts, dtype=np.int64).clip(0, 0xFFFFFFFF)
         recs["deadline_ms"] = deadlines
         return self.e.fork_batch(recs)
@@ -239,6 +248,7 @@ class EngineStore:
             for i, s in zip(batch, st):
                 statuses[i] = int(s)
             pending = rest
+        self._forget(conts, statuses)
         return statuses
 
     # core/recover-unprocessed-publish-messages (core.clj:193-201)
@@ -248,6 +258,7 @@ class EngineStore:
             conts, st, more = self.e.recover(now_ms)
             out += list(zip(self._conts(conts), [int(s) for s in st]))
             if not more:
+                self._forget([c for c, _ in out], [s for _, s in out])
                 return out
 
     # join-metadata + all-joins-status / all-joins (core.clj:63-66, redis.clj:242-253)
@@ -259,7 +270,7 @@ class EngineStore:
         return self._conts([meta], lens, mws, pay)[0]
 
     def store_in_publish_queue(self, barrier_id, at_ms):
-        lo, hi = self._fp(barrier_id)
+        lo, hi = self._fp(barrier_id, register=True)
         self.e.store_in_publish_queue(lo, hi, at_ms)
 
     def queue_scores(self, barrier_id):

@@ -17,7 +17,7 @@ def worker(rank, port, out_dir, extra=()):
                        "MASTER_PORT": str(port)})
     sys.path.insert(0, ROOT)
     sys.argv = ["bench.py", "--gpus", "2", "--steps", str(STEPS), "--warmup", "8", "--barriers", str(NB),
-                "--rehearse-on-one-gpu", "--no-cpu-baseline"] + list(extra)
+                "--rehearse-on-one-gpu", "--no-cpu-baseline", "--min-timed-ms", "1"] + list(extra)
     sys.stdout = open(os.path.join(out_dir, f"out_{rank}.txt"), "w")
     import bench
     bench.main()
@@ -34,7 +34,8 @@ def test_bench_with_two_ranks_on_one_gpu(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == STEPS and out["scaling"] == "weak"
     # every rank generates NB barriers per job; 16 steps = 2 jobs; every barrier fires exactly once
-    assert out["continuations_fired"] == 2 * NB * (STEPS // 8)
+    assert out["timed_steps"] == out["repeats"] * STEPS
+    assert out["continuations_fired"] == 2 * NB * (out["timed_steps"] // 8)
     assert out["value"] > 0 and out["roofline"]["kernel"] in out["kernels"]
 
 
@@ -51,4 +52,4 @@ def test_bench_with_a_hot_key_and_small_receive_buffers(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["value"] > 0
     # barriers that lost a position to the hot key never complete; the others fire once per job
-    assert 0 < out["continuations_fired"] < 2 * NB * (STEPS // 8)
+    assert 0 < out["continuations_fired"] < 2 * NB * (out["timed_steps"] // 8)

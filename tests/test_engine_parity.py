@@ -294,6 +294,43 @@ def test_checkpoint_load_rejects_other_geometry(tmp_path):
     b.close()
 
 
+def test_damaged_checkpoint_is_refused_before_the_engine_is_touched(oracle_lib, tmp_path):
+    """A truncated file, a flipped byte and a free list that names a unit outside the arena are all refused,
+    and the engine that tried to load them still holds exactly what it held (compared with the oracle).  A save
+    replaces its target only when the new file is complete: no .tmp file stays behind."""
+    import os
+    rng = np.random.default_rng(12)
+    nb = 60
+    ids = [f"ck{b}~t" for b in range(nb)]
+    counts = rng.integers(1, 9, nb)
+    e, o, d = make_pair(oracle_lib, ids, 64, capacity=nb)
+    try:
+        d.fork(np.arange(nb), counts, np.full(nb, T0 + 60_000))
+        jb = rng.integers(0, nb, 300)
+        pos = (rng.random(300) * counts[jb]).astype(np.int64)
+        d.join(jb, pos, np.full(300, 64), np.zeros(300, np.int64), payload_bytes(jb, pos, np.arange(300), 64), T0 + 5)
+        ec, oc = d.sweep(T0 + 6)
+        d.ack(ec, oc, lambda k: True, T0 + 7)          # frees slabs: the free lists are not empty
+        good = tmp_path / "good.ckpt"
+        e.checkpoint_save(good)
+        assert sorted(os.listdir(tmp_path)) == ["good.ckpt"]
+        raw = good.read_bytes()
+        for name, data in (("short.ckpt", raw[:len(raw) - 100]), ("long.ckpt", raw + b"x"),
+                           ("flip.ckpt", raw[:4000] + bytes([raw[4000] ^ 0x40]) + raw[4001:])):
+            bad = tmp_path / name
+            bad.write_bytes(data)
+            with pytest.raises(RuntimeError, match="truncated or damaged"):
+                e.checkpoint_load(bad)
+            d.check_all_snapshots()
+        # the state goes on after the refusals, and the good file still loads
+        d.join(jb[:50], pos[:50], np.full(50, 64), np.zeros(50, np.int64), payload_bytes(jb[:50], pos[:50], np.arange(50) + 7, 64), T0 + 9)
+        e.checkpoint_save(good)                         # over the old one
+        e.checkpoint_load(good)
+        d.check_all_snapshots()
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("hot_mode", [-1, 1])
 def test_messages_longer_than_a_row(oracle_lib, tmp_path, hot_mode):
     """Engine with 64-byte inline rows that accepts messages up to 2 KiB: 40 % of the messages take a
