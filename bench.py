@@ -493,7 +493,8 @@ def main():
         units = {   # algorithmic bytes per launch: per-unit figure x units.  Per event: 32 B header + 64 B table line
             # (link), 16 B presence update (resolve), message in + out (copy); per fired barrier 96 + 2cP;
             # per inserted barrier 160; per slot scanned 16
-            "join_link": (96, batch), "join_resolve": (16, batch), "join_copy": (2 * P, batch),
+            # (when the link pass copies the messages itself there is no copy launch and the 2P go to the link)
+            "join_link": (96 if "join_copy" in acc else 96 + 2 * P, batch), "join_resolve": (16, batch), "join_copy": (2 * P, batch),
             "join_complex": (0, 0), "pop": (16, eng.stats()["slots"]), "gather": (96 + 2 * c * P, fired_job / steps_per_job),
             "fork_claim": (96, nb), "fork_apply": (64, nb), "ack": (128, fired_job / steps_per_job),
             "compact": (2 * 72, eng.stats()["slots"])}     # table hygiene: every slot + queue word read and rewritten

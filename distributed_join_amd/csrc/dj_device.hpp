@@ -168,8 +168,11 @@ struct Work {
                                   // (cx_hot_span: a power of two, 1 .. 128)
     uint32_t* cx_nq;              // [CX_CAP] 1 when the barrier was not in the primary queue before the batch
     uint32_t cx_on;               // 1: this batch runs the parallel hot-barrier kernels
+    uint32_t publish_hints;       // 1: the link pass hands the previous batch's counters (the other bank) to the host
+    uint32_t fused;               // 1: the link pass has copied every accepted event's message into its row already; the
+                                  // resolve passes copy again where a later event of the batch wrote the same position
 };
-enum { C_COMPLEX = 1, C_MAXCHAIN = 2, C_CXPOOL = 3, C_MID = 4, C_COUNT = 8 };
+enum { C_COMPLEX = 1, C_MAXCHAIN = 2, C_CXPOOL = 3, C_MID = 4, C_RECOPY = 5, C_COUNT = 8 };
 constexpr uint32_t CX_CAP = 65536;     // barriers with long chains per batch handled by the parallel path
 constexpr uint32_t CX_HASH = 262144;   // power of two, >= 2 * CX_CAP
 constexpr uint32_t CX_HOT_STRIDE = 8;  // pool entries per table line (64 bytes)

@@ -60,6 +60,7 @@ struct dj_engine {
     std::recursive_mutex mu;     // entry points serialise themselves: callers may share an engine between threads
     Slot* slots_alt;             // second table for dj_compact (always all-empty between calls)
     uint64_t* q_alt;
+    int fuse_off;                // 1: the link pass never copies messages itself (dj_set_hot_path mode + 4: tests of the separate copy pass)
     int cx_force;                // -1: automatic; else bit 0: parallel hot-barrier kernels, bit 1: wide register replay (tests)
     unsigned int* h_maxchain;    // pinned: longest chain of the previous join batch (picks the hot-barrier kernels)
     uint64_t used_upper;         // upper bound of non-empty slots (live + tombstones) since the last compaction
@@ -350,6 +351,7 @@ extern "C" int dj_create(const dj_config* cfg, dj_engine** out) {
     e->h_maxchain = nullptr;
     e->compact_ev = nullptr;
     e->cx_force = -1;
+    e->fuse_off = 0;
     e->scratch_ptr = nullptr;
     for (int k = 0; k < DJ_PROF_KERNELS; ++k) { e->ev_start[k] = nullptr; e->ev_stop[k] = nullptr; e->ev_used[k] = 0; }
     int rc = create_impl(e);
@@ -379,8 +381,10 @@ extern "C" int dj_get_config(const dj_engine* e, dj_config* out) {
 }
 
 extern "C" int dj_set_hot_path(dj_engine* e, int mode) {
-    if (!e || mode < -1 || mode > 3) return DJ_E_INVALID;
+    if (!e || mode < -1 || mode > 7) return DJ_E_INVALID;
     std::lock_guard<std::recursive_mutex> guard(e->mu);
+    e->fuse_off = mode >= 4 ? 1 : 0;
+    if (mode >= 4) mode -= 4;
     e->cx_force = mode;
     return DJ_OK;
 }
@@ -558,10 +562,21 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
     // than the serial kernel's 256-entry chain copy go parallel, 2000 x 50 and 8000 x 12 stay serial).
     const unsigned int rounds = hint[0] / 2048 + 1;
     w.cx_on = serial_only ? 0u : e->cx_force >= 0 ? (uint32_t)(e->cx_force & 1) : ((uint64_t)rounds * hint[1] > 256 ? 1u : 0u);
-    if (w.cx_on)
-        LAUNCH(e, DJ_PROF_JOIN_LINK, (join_link_kernel<true><<<grid_for(n, LINK_BLOCK_HOT), LINK_BLOCK_HOT, 0, e->stream>>>(e->t, w, d_recs, n, pitch, d_status)));
-    else
-        LAUNCH(e, DJ_PROF_JOIN_LINK, (join_link_kernel<false><<<grid_for(n, LINK_BLOCK), LINK_BLOCK, 0, e->stream>>>(e->t, w, d_recs, n, pitch, d_status)));
+    // Fused form: the link pass copies every accepted event's message into its row itself (one pass less over the
+    // events, and the copy's streaming overlaps the link's atomics); the resolve passes copy a position again where
+    // several events of the batch wrote it.  Not with the parallel long-chain kernels (a barrier with thousands of
+    // events per batch would have every one of them write its few rows) and not with messages in blocks of their own.
+    w.fused = (!w.cx_on && e->t.max_message <= e->t.stride && e->fuse_off == 0) ? 1u : 0u;
+    const uint32_t lanes = e->cfg.payload_stride / 16;
+#define DJ_LINK(HOT, G, BLOCK) join_link_kernel<HOT, G><<<grid_for(n, BLOCK), BLOCK, 0, e->stream>>>(e->t, w, d_recs, n, pitch, d_status, d_payloads)
+    if (w.cx_on) LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINK(true, 0, LINK_BLOCK_HOT)));
+    else if (!w.fused) LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINK(false, 0, LINK_BLOCK)));
+    else if (lanes <= 4) LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINK(false, 4, LINK_BLOCK)));
+    else if (lanes <= 8) LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINK(false, 8, LINK_BLOCK)));
+    else if (lanes <= 16) LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINK(false, 16, LINK_BLOCK)));
+    else if (lanes <= 32) LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINK(false, 32, LINK_BLOCK)));
+    else LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINK(false, 64, LINK_BLOCK)));
+#undef DJ_LINK
     // h_maxchain[8] = barriers of the previous batch with 9..16 events: while there are thousands of them the
     // register replay takes chains up to 16 (slower for everyone else, far cheaper than a wave per barrier)
     const bool wide = e->cx_force >= 0 ? (e->cx_force & 2) != 0 : hint[8] >= WIDE_ON;
@@ -583,12 +598,15 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
         if (sb > 4096) sb = 4096;
         cx_scan_kernel<<<sb, 256, 0, e->stream>>>(w, n, now_ms);
         cx_finalize_kernel<<<1024, 64, 0, e->stream>>>(e->t, w, now_ms);
-        join_resolve_complex_kernel<<<cx_grid, 64, 0, e->stream>>>(e->t, w, (uint32_t)n, now_ms, d_status);
+        join_resolve_complex_kernel<<<cx_grid, 64, 0, e->stream>>>(e->t, w, (uint32_t)n, now_ms, d_status, d_recs, d_payloads, pitch);
         if (e->profiling) { (void)hipEventRecord(e->ev_stop[DJ_PROF_JOIN_COMPLEX], e->stream); e->ev_used[DJ_PROF_JOIN_COMPLEX] = 1; }
     } else {
-        LAUNCH(e, DJ_PROF_JOIN_COMPLEX, (join_resolve_complex_kernel<<<cx_grid, 64, 0, e->stream>>>(e->t, w, (uint32_t)n, now_ms, d_status)));
+        LAUNCH(e, DJ_PROF_JOIN_COMPLEX, (join_resolve_complex_kernel<<<cx_grid, 64, 0, e->stream>>>(e->t, w, (uint32_t)n, now_ms, d_status, d_recs, d_payloads, pitch)));
     }
-    const uint32_t lanes = e->cfg.payload_stride / 16;
+    if (w.fused) {
+        HIP_TRY(e, hipGetLastError());
+        return DJ_OK;
+    }
     if (lanes <= 4) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<4>(e, w, n, d_recs, d_payloads, pitch, d_status));
     else if (lanes <= 8) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<8>(e, w, n, d_recs, d_payloads, pitch, d_status));
     else if (lanes <= 16) LAUNCH(e, DJ_PROF_JOIN_COPY, launch_join_copy<16>(e, w, n, d_recs, d_payloads, pitch, d_status));
@@ -609,6 +627,7 @@ extern "C" int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs
     e->w.counters = e->d_counters + e->ctr_bank * C_COUNT;
     e->w.counters_next = e->d_counters + (e->ctr_bank ^ 1) * C_COUNT;
     e->ctr_bank ^= 1;
+    e->w.publish_hints = 1;
     return join_launch(e, e->w, false, n, d_recs, d_payloads, pitch, now_ms, d_status);
 }
 
@@ -631,6 +650,7 @@ extern "C" int dj_join_batch_static(dj_engine* e, uint32_t n, const dj_join_rec*
     w.complex_ = reinterpret_cast<uint32_t*>(p + SCR_COMPLEX);
     w.counters = reinterpret_cast<unsigned int*>(p + SCR_COUNTERS);
     w.counters_next = w.counters + C_COUNT;
+    w.publish_hints = 0;        // the second bank is a dummy here: the engine's own batches keep steering the kernel choice
     return join_launch(e, w, true, n, d_recs, d_payloads, pitch, now_ms, d_status);
 }
 

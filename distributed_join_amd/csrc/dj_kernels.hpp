@@ -132,9 +132,33 @@ __global__ void __launch_bounds__(FORK_APPLY_BLOCK) fork_apply_kernel(Table t, W
 // previous batch): blocks of 1024 with block-level pre-aggregation.
 constexpr int LINK_BLOCK = 256, LINK_BLOCK_HOT = 1024;
 
-template <bool HOT>
+// Copies the message of one event into its row, G lanes per message (wave-cooperative: the event's lane hands
+// its source and destination to the G lanes that move it).  The row is written in whole 64-byte lines
+// (zeros behind the message): a partly written line costs a read-modify-write in memory.
+template <int G>
+__device__ inline void wave_copy_rows(const Table& t, const uint8_t* payloads, uint64_t pitch, uint64_t ev0, uint64_t row_off,
+                                      uint32_t len) {
+    constexpr int EPS = 64 / G;                     // events per step
+    const uint32_t lane = threadIdx.x & 63, sub = lane / G, j0 = lane % G;
+    const uint32_t rlo = (uint32_t)row_off, rhi = (uint32_t)(row_off >> 32);
+#pragma unroll 1
+    for (int step = 0; step < G; ++step) {
+        const int src = step * EPS + (int)sub;
+        const uint64_t row = ((uint64_t)__shfl(rhi, src) << 32) | __shfl(rlo, src);
+        const uint32_t ln = __shfl(len, src);
+        if (row == ~0ull) continue;
+        const uint4* from = reinterpret_cast<const uint4*>(payloads + (ev0 + (uint64_t)src) * pitch);
+        uint4* to = reinterpret_cast<uint4*>(t.arena + row);
+        const uint32_t chunks = (ln + 15) >> 4, full = (chunks + 3) & ~3u;
+        for (uint32_t c = j0; c < full; c += G) nt_store(&to[c], c < chunks ? nt_load(&from[c]) : make_uint4(0, 0, 0, 0));
+    }
+}
+
+// G > 0: fused form, the pass also copies the messages (G lanes each) and stores the {len, max-wait} words;
+// payloads may then not be null.  G = 0: the copy pass does that later.
+template <bool HOT, int G>
 __global__ void __launch_bounds__(HOT ? LINK_BLOCK_HOT : LINK_BLOCK)
-join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t pitch, int32_t* status) {
+join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t pitch, int32_t* status, const uint8_t* payloads) {
     // Block-level pre-aggregation for barriers flagged hot: their events are chained inside the block
     // through LDS and the block issues ONE exchange per hot barrier (a queued returning atomic costs
     // ~40 ns, ten thousand of them on one word would serialise the whole pass).  Up to HOT_KEYS hot
@@ -151,7 +175,19 @@ join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t 
         __syncthreads();
     }
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    // the previous batch's counters (the bank this batch does not use) are final: to the host's memory, then to zero
+    // for the next batch
+    if (blockIdx.x == 0 && threadIdx.x < C_COUNT) {
+        if (w.publish_hints) {
+            if (threadIdx.x == C_COMPLEX) w.hint[0] = w.counters_next[C_COMPLEX];
+            if (threadIdx.x == C_MAXCHAIN) w.hint[1] = w.counters_next[C_MAXCHAIN];
+            if (threadIdx.x == C_MID) w.hint[8] = w.counters_next[C_MID];
+        }
+        w.counters_next[threadIdx.x] = 0;
+    }
     uint32_t slot = 0;
+    uint64_t row_off = ~0ull;      // fused form: byte offset of the event's row in the arena
+    uint32_t row_len = 0;
     bool stores_meta = false;      // this event writes its position's {len, max-wait} word
     int agg_key = -1;
     uint32_t agg_rank = 0, agg_pos = 0, agg_mw = 0;
@@ -174,7 +210,7 @@ join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t 
         }
         if (st != 0) {
             status[i] = st;
-            w.dst[i] = NODST;
+            if (G == 0) w.dst[i] = NODST;
             w.ev_slot[i] = 0xFFFFFFFFu;
         } else {
             // the common answers are written here, coalesced; the resolve pass only overwrites the
@@ -184,9 +220,16 @@ join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t 
             // or when the barrier has seen such a position before (META_PMD, sticky until the next fork)
             const bool pm = (info.y & META_PMD) || b.y != t.stride || b.z != 0;
             stores_meta = pm;
-            w.dst[i] = dst_pack(info.z, info.x, b.x) | (pm ? DST_PM : 0ull) | (b.y == t.stride ? DST_FULL : 0ull) |
-                       ((info.y & META_OVF) ? DST_OVF : 0ull);
+            if (G == 0)
+                w.dst[i] = dst_pack(info.z, info.x, b.x) | (pm ? DST_PM : 0ull) | (b.y == t.stride ? DST_FULL : 0ull) |
+                           ((info.y & META_OVF) ? DST_OVF : 0ull);
             if (pm && !(info.y & META_PMD)) atomicOr(&t.slots[s].meta, META_PMD);
+            if (G > 0) {
+                const uint32_t k = class_of(info.x);
+                row_off = (uint64_t)info.z * 64 + slab_payload_off(k) + (uint64_t)b.x * t.stride;
+                row_len = b.y;
+                if (pm) slab_posmeta(t, info.z, k)[b.x] = make_uint2(b.y, b.z);
+            }
             slot = (uint32_t)s;
             w.ev_slot[i] = slot;
             if (HOT && (info.y & META_HOT)) {
@@ -235,6 +278,7 @@ join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t 
         const uint32_t prev = a_xchg(&t.slots[slot].chain, i + 1);
         w.node[i] = node_pack(prev, x_pos, x_mw);
     }
+    if constexpr (G > 0) wave_copy_rows<G>(t, payloads, pitch, (uint64_t)i - (threadIdx.x & 63), row_off, row_len);
     // a sample for the host: how ragged is the traffic (it decides how the next barriers are forked)
     if (blockIdx.x == 0 && threadIdx.x < 256) {
         const uint64_t m = __ballot(stores_meta);
@@ -362,7 +406,18 @@ join_resolve_kernel(Table t, Work w, uint32_t n, uint64_t now, int32_t* status) 
 #pragma unroll
                 for (int k = 0; k < CR; ++k)
                     if (!(done & (1u << k)) && idx[k] != 0xFFFFFFFFu && node_pos(nd[k]) == pos) last = false;
-                if (!last) w.dst[best] = NODST;
+                if (!w.fused) {
+                    if (!last) w.dst[best] = NODST;
+                } else if (last) {
+                    // every event has copied its message already, in no order: where earlier events of the batch
+                    // wrote this position too, the last writer copies again (HSET: the last write stays)
+                    bool again = false;
+#pragma unroll
+                    for (int k = 0; k < CR; ++k)
+                        if ((done & (1u << k)) && (uint32_t)k != bk && node_pos(nd[k]) == pos) again = true;
+                    // (rare: the event goes on a list that the pass for long chains works off, a wave per message)
+                    if (again) w.dst[atomicAdd(&w.counters[C_RECOPY], 1u)] = best;
+                }
             }
             store_ts_bits(sl, now, count > 64 ? (uint64_t)r.arrived : r.bits);   // SET <id>:join-ts, redis.clj:136
             sl->chain = 0;
@@ -435,7 +490,8 @@ __device__ inline void for_events_of_slot(const Work& w, uint32_t n, uint32_t s,
 // from its last index.
 // This kernel is the serial form: lane 0 walks the chain.  It handles every long chain when the
 // parallel kernels below are off, and the barriers they could not register when they are on.
-__global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work w, uint32_t n, uint64_t now, int32_t* status) {
+__global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work w, uint32_t n, uint64_t now, int32_t* status,
+                                                                  const dj_join_rec* recs, const uint8_t* payloads, uint64_t pitch) {
     __shared__ uint32_t fmin[1024];
     __shared__ uint32_t fmax[1024];
     // the chain as lane 0 found it (link words and event indices): the answers are then written by all lanes
@@ -451,6 +507,21 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
     const uint32_t lane = threadIdx.x;
     const uint32_t nc = w.counters[C_COMPLEX];
     uint32_t n_mid = 0;        // chains the wide register replay would have taken (lane 0 counts)
+    if (w.fused) {
+        // messages the register replay wants copied again (the last of several writers of one position)
+        const uint32_t nre = w.counters[C_RECOPY];
+        for (uint32_t k = blockIdx.x; k < nre; k += gridDim.x) {
+            const uint32_t ev = (uint32_t)w.dst[k];
+            const Slot* sl = &t.slots[w.ev_slot[ev]];
+            const uint32_t kcls = class_of(sl->count), slab = sl->slab;
+            const uint4 b = reinterpret_cast<const uint4*>(recs)[2 * (size_t)ev + 1];     // position, len, max_wait
+            const uint4* from = reinterpret_cast<const uint4*>(payloads + (uint64_t)ev * pitch);
+            uint4* to = reinterpret_cast<uint4*>(slab_payload(t, slab, kcls) + (uint64_t)b.x * t.stride);
+            const uint32_t chunks = (b.y + 15) >> 4, full = (chunks + 3) & ~3u;
+            for (uint32_t c = lane; c < full; c += 64) to[c] = c < chunks ? from[c] : make_uint4(0, 0, 0, 0);
+            if (lane == 0 && ((sl->meta & META_PMD) || b.y != t.stride || b.z != 0)) slab_posmeta(t, slab, kcls)[b.x] = make_uint2(b.y, b.z);
+        }
+    }
     for (uint32_t c = blockIdx.x; c < nc; c += gridDim.x) {
         if (w.cx_on && c < CX_CAP && w.cx_off[c] != IDX_NONE) continue;       // the parallel kernels have it
         const uint32_t s = w.complex_[c];
@@ -536,7 +607,7 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
             else if (mw && pa_pre == NQ) st = DJ_JOIN_NEAREST_NOT_QUEUED;
             else if (mw) at = now + 1000ull * mw;
             if (st != DJ_JOIN_WAITING) status[i] = st;
-            if (fmax[pos] != i + 1) w.dst[i] = NODST;
+            if (!w.fused && fmax[pos] != i + 1) w.dst[i] = NODST;
             return at;
         };
         if (scan) {                               // all lanes, over the batch once more
@@ -560,6 +631,22 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
         for (int off = 32; off > 0; off >>= 1) {
             const uint64_t o = ((uint64_t)__shfl_xor((uint32_t)(at_min >> 32), off) << 32) | __shfl_xor((uint32_t)at_min, off);
             if (o < at_min) at_min = o;
+        }
+        if (w.fused) {
+            // every event has copied its message already, in no order: a position that several events of the batch
+            // wrote gets its last writer's message again (HSET: the last write stays), by the whole wave
+            const uint32_t kcls = class_of(count);
+            const bool stored = (sl->meta & META_PMD) != 0;
+            for (uint32_t p = 0; p < count; ++p) {
+                const uint32_t last = fmax[p];
+                if (last == 0 || fmin[p] + 1 == last) continue;           // untouched, or one writer
+                const uint4 b = reinterpret_cast<const uint4*>(recs)[2 * (size_t)(last - 1) + 1];     // position, len, max_wait
+                const uint4* from = reinterpret_cast<const uint4*>(payloads + (uint64_t)(last - 1) * pitch);
+                uint4* to = reinterpret_cast<uint4*>(slab_payload(t, slab, kcls) + (uint64_t)p * t.stride);
+                const uint32_t chunks = (b.y + 15) >> 4, full = (chunks + 3) & ~3u;
+                for (uint32_t c = lane; c < full; c += 64) to[c] = c < chunks ? from[c] : make_uint4(0, 0, 0, 0);
+                if (lane == 0 && (stored || b.y != t.stride || b.z != 0)) slab_posmeta(t, slab, kcls)[p] = make_uint2(b.y, b.z);
+            }
         }
         if (lane == 0) {
             sl->bits = count > 64 ? (uint64_t)arrived : bits0;
@@ -802,13 +889,6 @@ __global__ void __launch_bounds__(256) join_copy_kernel(Table t, Work w, const d
     const uint32_t sub = lane / G, j0 = lane % G;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    // the next batch's counters (the bank this batch does not use) start at zero
-    if (blockIdx.x == 0 && threadIdx.x < C_COUNT) w.counters_next[threadIdx.x] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {      // final since the resolve passes; straight into the host's memory
-        w.hint[0] = w.counters[C_COMPLEX];
-        w.hint[1] = w.counters[C_MAXCHAIN];
-        w.hint[8] = w.counters[C_MID];
-    }
     const bool hot = w.cx_on && w.counters[C_COMPLEX] != 0;
     for (uint64_t base = wave * EPW; base < n; base += waves * EPW) {
         const uint64_t i = base + sub;
@@ -855,12 +935,6 @@ __global__ void __launch_bounds__(256) join_copy_long_kernel(Table t, Work w, co
     const uint32_t sub = lane / G, j0 = lane % G;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6;
     const uint64_t waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    if (blockIdx.x == 0 && threadIdx.x < C_COUNT) w.counters_next[threadIdx.x] = 0;
-    if (blockIdx.x == 0 && threadIdx.x == 0) {      // final since the resolve passes; straight into the host's memory
-        w.hint[0] = w.counters[C_COMPLEX];
-        w.hint[1] = w.counters[C_MAXCHAIN];
-        w.hint[8] = w.counters[C_MID];
-    }
     const bool hot = w.cx_on && w.counters[C_COMPLEX] != 0;
     for (uint64_t base = wave * EPW; base < n; base += waves * EPW) {      // uniform across the wave
         const uint64_t i = base + sub;

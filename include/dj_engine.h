@@ -296,7 +296,9 @@ int dj_checkpoint_load(dj_engine* e, const char* path);
  * chain of the previous batch.  Both forms give identical results; this call pins the choice
  * (-1 automatic, 0 serial, 1 parallel) so tests can exercise each.  Likewise the per-thread replay of
  * short chains has a form for up to 8 events and one for up to 16, picked from the previous batch:
- * adding 2 to the mode (2 serial, 3 parallel) pins the second, 0 and 1 pin the first.  No reference
+ * adding 2 to the mode (2 serial, 3 parallel) pins the second, 0 and 1 pin the first.  Messages that
+ * fit a payload row are copied into the table by the first pass over the events itself when the serial
+ * form runs; adding 4 (modes 4..7) keeps the separate copy pass that the other cases use.  No reference
  * counterpart. */
 int dj_set_hot_path(dj_engine* e, int mode);
 

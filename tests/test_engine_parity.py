@@ -104,7 +104,7 @@ def run_oplog(d, rng, n_barriers, counts, stride, rounds, batch, hot=None, var_l
     d.check_all_snapshots()
 
 
-@pytest.mark.parametrize("hot_mode", [-1, 1, 2, 3])
+@pytest.mark.parametrize("hot_mode", [-1, 1, 2, 3, 4, 6])
 def test_small_counts_many_duplicates(oracle_lib, hot_mode):
     rng = np.random.default_rng(1)
     nb = 40
@@ -117,7 +117,7 @@ def test_small_counts_many_duplicates(oracle_lib, hot_mode):
         e.close()
 
 
-@pytest.mark.parametrize("hot_mode", [-1, 0, 2])
+@pytest.mark.parametrize("hot_mode", [-1, 0, 2, 4])
 def test_thousands_of_barriers_with_ten_events_a_batch(oracle_lib, hot_mode):
     """About ten events per barrier and batch on thousands of barriers: chains of 9..16 events, which the
     engine (left to itself) moves from the long-chain kernels to the 16-event register replay after the first
@@ -133,7 +133,7 @@ def test_thousands_of_barriers_with_ten_events_a_batch(oracle_lib, hot_mode):
         e.close()
 
 
-@pytest.mark.parametrize("hot_mode", [-1, 0, 1])
+@pytest.mark.parametrize("hot_mode", [-1, 0, 1, 4])
 def test_hot_barrier_long_chains(oracle_lib, hot_mode):
     rng = np.random.default_rng(2)
     nb = 30
@@ -180,7 +180,7 @@ def test_many_hot_barriers_at_once(oracle_lib, hot_mode):
         e.close()
 
 
-@pytest.mark.parametrize("hot_mode", [-1, 0, 1])
+@pytest.mark.parametrize("hot_mode", [-1, 0, 1, 4])
 def test_large_counts_multiword_bitmaps(oracle_lib, hot_mode):
     rng = np.random.default_rng(3)
     nb = 12
