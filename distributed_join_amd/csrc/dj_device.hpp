@@ -145,7 +145,10 @@ struct Work {
     uint64_t* dst;       // join: where the event's message goes, NODST = superseded / rejected
     uint32_t* ev_slot;   // join: slot of event i (0xFFFFFFFF when the event was refused)
     uint32_t* complex_;  // slots whose chain is too long for the register path
-    uint32_t* slot_of;   // fork: slot of record i
+    uint32_t* slot_of;   // fork: slot of record i; SLOT_CREATED set when the record's own claim made the slot
+    unsigned int* fork_contested;        // fork: set by a record whose barrier existed already (from before the batch or made by
+                                         // another record of it); while zero every record owns a fresh slot and wins it
+    unsigned int* fork_contested_next;   // the next fork batch's word, zeroed by this one
     uint32_t* cont_slot; // sweep: slot of continuation k
     unsigned int* counters;       // C_* below, bank of the current join batch
     unsigned int* counters_next;  // the other bank: zeroed by the current batch for the next one
@@ -172,6 +175,7 @@ struct Work {
     uint32_t fused;               // 1: the link pass has copied every accepted event's message into its row already; the
                                   // resolve passes copy again where a later event of the batch wrote the same position
 };
+constexpr uint32_t SLOT_CREATED = 0x80000000u;      // tables have at most 2^30 slots
 enum { C_COMPLEX = 1, C_MAXCHAIN = 2, C_CXPOOL = 3, C_MID = 4, C_RECOPY = 5, C_COUNT = 8 };
 constexpr uint32_t CX_CAP = 65536;     // barriers with long chains per batch handled by the parallel path
 constexpr uint32_t CX_HASH = 262144;   // power of two, >= 2 * CX_CAP

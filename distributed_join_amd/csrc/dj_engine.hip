@@ -71,6 +71,8 @@ struct dj_engine {
     uint64_t claimed_since_compact;
     int ctr_bank, sweep_bank;    // which half of the double-banked scratch the next call uses
     unsigned int* d_counters;    // 2 x C_COUNT
+    unsigned int* d_fork_contested;      // 2 words: this fork batch's and the next one's (see Work::fork_contested)
+    int fork_bank;
     unsigned long long* d_sweep; // 2 x S_COUNT
     unsigned long long* d_due;   // the two banks of the sweep's scan bound (Table::due_min points to one of them)
     // optional per-kernel timing (dj_profile_enable): one event pair per kernel id
@@ -292,6 +294,8 @@ static int create_impl(dj_engine* e) {
     ALLOC(e, w.complex_, nb * 4);
     ALLOC(e, w.slot_of, nb * 4);
     ALLOC(e, w.cont_slot, (nb > slots ? nb : slots) * 4);
+    ALLOC(e, e->d_fork_contested, 2 * 4);
+    HIP_TRY(e, hipMemsetAsync(e->d_fork_contested, 0, 2 * 4, e->stream));
     ALLOC(e, e->d_counters, 2 * C_COUNT * 4);
     HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 2 * C_COUNT * 4, e->stream));
     ALLOC(e, w.cx_keys, CX_HASH * 4);
@@ -309,7 +313,7 @@ static int create_impl(dj_engine* e) {
     w.hint = e->h_maxchain;       // hipHostMalloc memory is addressable from the device
     ALLOC(e, e->d_sweep, 2 * S_COUNT * 8);
     HIP_TRY(e, hipMemsetAsync(e->d_sweep, 0, 2 * S_COUNT * 8, e->stream));
-    e->ctr_bank = e->sweep_bank = 0;
+    e->ctr_bank = e->sweep_bank = e->fork_bank = 0;
     w.counters = e->d_counters;
     w.counters_next = e->d_counters + C_COUNT;
     w.sweep = e->d_sweep;
@@ -518,7 +522,13 @@ extern "C" int dj_fork_batch(dj_engine* e, uint32_t n, const dj_fork_rec* d_recs
     }
     e->used_upper += n;
     e->claimed_since_compact += n;
-    LAUNCH(e, DJ_PROF_FORK_CLAIM, (fork_claim_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, d_recs, n, d_status)));
+    e->w.fork_contested = e->d_fork_contested + e->fork_bank;
+    e->w.fork_contested_next = e->d_fork_contested + (e->fork_bank ^ 1);
+    e->fork_bank ^= 1;
+    if (e->profiling) (void)hipEventRecord(e->ev_start[DJ_PROF_FORK_CLAIM], e->stream);
+    fork_claim_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, d_recs, n, d_status);
+    fork_contest_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, n);
+    if (e->profiling) { (void)hipEventRecord(e->ev_stop[DJ_PROF_FORK_CLAIM], e->stream); e->ev_used[DJ_PROF_FORK_CLAIM] = 1; }
     LAUNCH(e, DJ_PROF_FORK_APPLY, (fork_apply_kernel<<<grid_for(n, FORK_APPLY_BLOCK), FORK_APPLY_BLOCK, 0, e->stream>>>(e->t, e->w, d_recs, n, d_status)));
     HIP_TRY(e, hipGetLastError());
     return DJ_OK;

@@ -11,14 +11,18 @@ namespace dj {
 // fork: redis/fork (redis.clj:90-104) + store-in-publish-queue at the deadline (core.clj:30)
 // =====================================================================================
 
-// pass 1: find or claim the slot of every record; the highest record index per slot wins
-// (a later /v1/fork of the same barrier fully resets an earlier one, redis.clj:97-103).
+// pass 1: find or claim the slot of every record.  The highest record index per slot wins (a later /v1/fork
+// of the same barrier fully resets an earlier one, redis.clj:97-103): a record that finds its barrier in the
+// table raises the slot's winner word to its index + 1 and marks the batch contested.  A record whose claim
+// made the slot does neither: in a batch that nobody contests it owns the slot, and the apply pass then neither
+// needs the winner word nor reads the slot at all (an atomic and a random read less per barrier).
 __global__ void __launch_bounds__(256) fork_claim_kernel(Table t, Work w, const dj_fork_rec* recs, uint32_t n,
                                                          int32_t* status) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     // ring pops of the apply pass stop at the tails as they are now (nothing is pushed or popped
     // during this pass), see wave_slab_alloc
     if (blockIdx.x == 0 && threadIdx.x < NUM_CLASSES) t.ring_tail_snap[threadIdx.x] = t.ring_tail[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *w.fork_contested_next = 0;
     if (i >= n) return;
     const ulonglong2 a = reinterpret_cast<const ulonglong2*>(recs)[2 * (size_t)i];
     const uint32_t count = recs[i].count;
@@ -34,9 +38,22 @@ __global__ void __launch_bounds__(256) fork_claim_kernel(Table t, Work w, const 
         w.slot_of[i] = 0xFFFFFFFFu;
         return;
     }
-    w.slot_of[i] = (uint32_t)s;
-    a_max(&t.slots[s].chain, i + 1);
+    w.slot_of[i] = (uint32_t)s | (created ? SLOT_CREATED : 0u);
+    if (!created) {
+        a_max(&t.slots[s].chain, i + 1);
+        *w.fork_contested = 1;
+    }
     status[i] = DJ_FORK_CREATED;
+}
+
+// pass 1b, only in a contested batch: the records that made their slots enter the contest too (another record of
+// the batch may name the same barrier, before or after them).
+__global__ void __launch_bounds__(256) fork_contest_kernel(Table t, Work w, uint32_t n) {
+    if (*w.fork_contested == 0) return;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t so = w.slot_of[i];
+    if (so != 0xFFFFFFFFu && (so & SLOT_CREATED)) a_max(&t.slots[so & ~SLOT_CREATED].chain, i + 1);
 }
 
 // pass 2: the winning record of each slot resets the barrier.
@@ -52,19 +69,23 @@ __global__ void __launch_bounds__(FORK_APPLY_BLOCK) fork_apply_kernel(Table t, W
     const bool long_on = t.max_message > t.stride;
     dj_fork_rec r = {};
     Slot* sl = nullptr;
+    const bool contested = *w.fork_contested != 0;
     if (i < n) s = w.slot_of[i];
     if (s != 0xFFFFFFFFu) {
+        s &= ~SLOT_CREATED;
         sl = &t.slots[s];
-        active = sl->chain == i + 1;   // an equal barrier-id later in the batch supersedes this record
+        active = !contested || sl->chain == i + 1;   // an equal barrier-id later in the batch supersedes this record
     }
     if (active) {
         r = recs[i];
         k_new = class_of(r.count);
-        old_slab = sl->slab;
-        old_count = sl->count;
+        if (contested) {            // otherwise the slot is this record's own, claimed empty: nothing to read
+            old_slab = sl->slab;
+            old_count = sl->count;
+            had_long = long_on && (sl->meta & META_OVF) != 0;
+        }
         k_old = class_of(old_count);
         need = old_slab == 0 || k_old != k_new;
-        had_long = long_on && (sl->meta & META_OVF) != 0;
     }
     // phase B (block-cooperative): one ring pop + one bump add per block
     const uint32_t fresh = block_slab_alloc(t, need, k_new, lds);

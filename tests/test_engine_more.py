@@ -1001,3 +1001,64 @@ def capi_memcpy(dst_tensor, src_ptr, nbytes):
         fn = hip.hipMemcpy
     fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
     return fn(dst_tensor.data_ptr(), src_ptr, nbytes, 3) == 0      # hipMemcpyDeviceToDevice
+
+
+@pytest.mark.gpu
+def test_fork_batches_with_and_without_contested_barriers():
+    """The highest record of a barrier in a fork batch wins (redis.clj:97-103), whichever of its records made the
+    slot; a batch of new barriers only (no record finds its barrier in the table) takes the pass without the
+    winner word and must leave the same table."""
+    from distributed_join_amd import capi
+    from distributed_join_amd.engine import FORK_REC
+    e = _engine(capacity_barriers=1 << 16, arena_bytes=1 << 30, max_count=999, payload_stride=64, max_batch=1 << 15)
+    rng = np.random.default_rng(5)
+
+    def recs_for(ids, counts):
+        r = np.zeros(len(ids), dtype=FORK_REC)
+        r["fp_lo"] = ids * 2 + 2
+        r["fp_hi"] = ids + 77
+        r["count"] = counts
+        r["deadline_ms"] = 1_700_000_000_000 + ids
+        return r
+
+    def check(ids, want):
+        for b, c in zip(ids.tolist(), want.tolist()):
+            meta, lens, _, _ = e.snapshot_one(b * 2 + 2, b + 77)
+            assert int(meta["count"]) == c and len(lens) == c and (lens == capi.DJ_NIL).all()
+
+    # 1. new barriers only
+    ids = np.arange(20000, dtype=np.uint64)
+    counts = rng.integers(1, 40, len(ids)).astype(np.uint32)
+    st = e.fork_batch(recs_for(ids, counts))
+    assert (st == capi.DJ_FORK_CREATED).all()
+    pick = rng.choice(len(ids), 300, replace=False)
+    check(ids[pick], counts[pick])
+    # 2. new barriers, each named two to four times in the batch: the last record's count stays
+    base = np.arange(30000, 36000, dtype=np.uint64)
+    reps = rng.integers(2, 5, len(base))
+    ids2 = np.repeat(base, reps)
+    order = rng.permutation(len(ids2))
+    ids2 = ids2[order]
+    counts2 = rng.integers(1, 40, len(ids2)).astype(np.uint32)
+    st = e.fork_batch(recs_for(ids2, counts2))
+    assert (st == capi.DJ_FORK_CREATED).all()
+    last = {}
+    for b, c in zip(ids2.tolist(), counts2.tolist()):
+        last[b] = c
+    pick = rng.choice(base, 300, replace=False)
+    check(pick, np.array([last[int(b)] for b in pick]))
+    # 3. one known barrier among new ones
+    ids3 = np.concatenate([np.arange(40000, 41000, dtype=np.uint64), ids[:1]])
+    counts3 = np.full(len(ids3), 7, np.uint32)
+    st = e.fork_batch(recs_for(ids3, counts3))
+    assert (st == capi.DJ_FORK_CREATED).all()
+    check(ids3[-3:], counts3[-3:])
+    check(ids[1:4], counts[1:4])
+    # 4. and a batch of new ones again after a contested one
+    ids4 = np.arange(50000, 52000, dtype=np.uint64)
+    counts4 = rng.integers(1, 999, len(ids4)).astype(np.uint32)
+    e.fork_batch(recs_for(ids4, counts4))
+    pick = rng.choice(len(ids4), 100, replace=False)
+    check(ids4[pick], counts4[pick])
+    assert e.stats()["live"] == 20000 + 6000 + 1000 + 2000
+    e.close()
