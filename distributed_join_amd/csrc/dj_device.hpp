@@ -41,6 +41,14 @@ constexpr uint32_t META_PMD = 8u;      // some position holds (or held) a messag
                                        // max-wait: the per-position {len, max_wait} words are authoritative.  Without the
                                        // flag every present position is {payload_stride, 0}; the words (pre-filled with
                                        // that value at fork) are then neither written by joins nor read by gathers
+// Bits 4..7 of meta: size class of the barrier's slab + 1 where that is not class_of(count), else 0.  Only a failed
+// publish can make them differ: it writes its metadata snapshot back (redis.clj:106-111) and the snapshot's :count may
+// be older than the barrier (re-forked with another :count meanwhile).  The messages stored under the other count stay
+// where they are, are counted by HLEN as before and are invisible to reads beyond the new :count, so the slab keeps
+// (or grows to) the larger class and the presence word or bitmap keeps covering all its positions.
+constexpr uint32_t META_KX_SHIFT = 4;
+constexpr uint32_t META_KX_MASK = 0xFu << META_KX_SHIFT;
+constexpr uint32_t META_KEEP = META_OVF | META_PMD | META_KX_MASK;     // what a rewrite of the retry counters leaves alone
 constexpr int OVF_CLASSES = 15;        // blocks for long messages: 1 << k units, 64 B .. 1 MiB
 constexpr uint32_t RETRY_NIL = 0xFFu;  // retry counter absent
 constexpr int NUM_CLASSES = 11;        // 1, 2, 4 ... 1024 positions
@@ -85,6 +93,13 @@ __host__ __device__ inline uint32_t class_of(uint32_t count) {
     return k;
 }
 __host__ __device__ inline uint32_t class_positions(uint32_t k) { return 1u << k; }
+// size class of the slab of a barrier with this :count and meta word (see META_KX_MASK)
+__host__ __device__ inline uint32_t slab_class(uint32_t count, uint32_t meta) {
+    const uint32_t kx = (meta >> 4) & 0xFu;
+    return kx ? kx - 1 : class_of(count);
+}
+// presence is a bitmap in the slab (and Slot::bits a counter) for classes above 64 positions, else the word Slot::bits
+__host__ __device__ inline bool class_has_bitmap(uint32_t k) { return k > 6; }
 __host__ __device__ inline uint32_t slab_bitmap_bytes(uint32_t k) {
     uint32_t p = 1u << k;
     return p > 64 ? ((p / 64 * 8 + 63) & ~63u) : 0;
@@ -667,6 +682,27 @@ __device__ inline void wave_release_long_each(const Table& t, bool mine, uint32_
     }
 }
 
+// Every lane of the wave calls this; a lane with `mine` owns a barrier that moves from slab `from` (class kf) to the
+// larger slab `to` (class kt): the {len, max-wait} words and the rows of all positions of the old class are copied by
+// the whole wave (a long message's reference moves with its row), the new positions get the default word.
+__device__ inline void wave_carry_each(const Table& t, bool mine, uint32_t from, uint32_t kf, uint32_t to, uint32_t kt) {
+    uint64_t todo = __ballot(mine);
+    const uint32_t lane = lane_id();
+    while (todo) {
+        const int l = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        const uint32_t f = __shfl(from, l), a = __shfl(kf, l), d = __shfl(to, l), b = __shfl(kt, l);
+        const uint32_t np = class_positions(a), nq = class_positions(b);
+        const uint2* pf = slab_posmeta(t, f, a);
+        uint2* pt = slab_posmeta(t, d, b);
+        for (uint32_t p = lane; p < nq; p += 64) pt[p] = p < np ? pf[p] : make_uint2(t.stride, 0);
+        const uint4* rf = reinterpret_cast<const uint4*>(slab_payload(t, f, a));
+        uint4* rt = reinterpret_cast<uint4*>(slab_payload(t, d, b));
+        const uint64_t chunks = (uint64_t)np * (t.stride >> 4);
+        for (uint64_t c = lane; c < chunks; c += 64) rt[c] = rf[c];
+    }
+}
+
 // A slab that starts a new life (fork): every position's {len, max_wait} word holds the value that
 // needs no write later, a full row without max-wait (so no position holds a long message either).
 // The area is a multiple of 64 bytes.
@@ -692,8 +728,8 @@ constexpr uint64_t DST_FULL = 1ull << 46;   // the message fills its row exactly
 constexpr uint64_t DST_OVF = 1ull << 47;    // the barrier holds (or held) long messages: the position's old length matters
 constexpr uint64_t DST_CX = 1ull << 48;     // set by cx_scan: the event's barrier is registered with the parallel long-chain kernels
 constexpr uint64_t DST_PM = 1ull << 62;     // also write the position's {len, max_wait}
-__device__ inline uint64_t dst_pack(uint32_t slab, uint32_t count, uint32_t pos) {
-    return (uint64_t)slab | ((uint64_t)class_of(count) << 32) | ((uint64_t)pos << 36);
+__device__ inline uint64_t dst_pack(uint32_t slab, uint32_t k, uint32_t pos) {
+    return (uint64_t)slab | ((uint64_t)k << 32) | ((uint64_t)pos << 36);
 }
 __device__ inline uint32_t dst_class(uint64_t d) { return (uint32_t)(d >> 32) & 15u; }
 __device__ inline uint32_t dst_pos(uint64_t d) { return (uint32_t)(d >> 36) & 0x3FFu; }

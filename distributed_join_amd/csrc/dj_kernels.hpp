@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(FORK_APPLY_BLOCK) fork_apply_kernel(Table t, W
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     // phase A (per lane): is this record the winner of its slot, and does the slot need a new slab
     bool active = false, need = false, had_long = false;
-    uint32_t s = 0xFFFFFFFFu, k_new = 0, k_old = 0, old_slab = 0, old_count = 0;
+    uint32_t s = 0xFFFFFFFFu, k_new = 0, k_old = 0, old_slab = 0, old_count = 0, old_meta = 0;
     const bool long_on = t.max_message > t.stride;
     dj_fork_rec r = {};
     Slot* sl = nullptr;
@@ -82,15 +82,17 @@ __global__ void __launch_bounds__(FORK_APPLY_BLOCK) fork_apply_kernel(Table t, W
         if (contested) {            // otherwise the slot is this record's own, claimed empty: nothing to read
             old_slab = sl->slab;
             old_count = sl->count;
-            had_long = long_on && (sl->meta & META_OVF) != 0;
+            old_meta = sl->meta;
+            had_long = long_on && (old_meta & META_OVF) != 0;
         }
-        k_old = class_of(old_count);
+        k_old = slab_class(old_count, old_meta);
         need = old_slab == 0 || k_old != k_new;
     }
     // phase B (block-cooperative): one ring pop + one bump add per block
     const uint32_t fresh = block_slab_alloc(t, need, k_new, lds);
     // a barrier that is reset gives its long-message blocks back (not when the reset is refused below)
-    if (long_on) wave_release_long_each(t, had_long && !(need && fresh == 0), old_slab, k_old, 0, old_count);
+    if (long_on) wave_release_long_each(t, had_long && !(need && fresh == 0), old_slab, k_old, 0,
+                                        (old_meta & META_KX_MASK) ? class_positions(k_old) : old_count);
     block_slab_free(t, need && fresh != 0, k_old, old_slab, lds);
     // phase C (per lane)
     __shared__ unsigned long long due_lo;
@@ -241,12 +243,12 @@ join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t 
             // or when the barrier has seen such a position before (META_PMD, sticky until the next fork)
             const bool pm = (info.y & META_PMD) || b.y != t.stride || b.z != 0;
             stores_meta = pm;
+            const uint32_t k = slab_class(info.x, info.y);
             if (G == 0)
-                w.dst[i] = dst_pack(info.z, info.x, b.x) | (pm ? DST_PM : 0ull) | (b.y == t.stride ? DST_FULL : 0ull) |
+                w.dst[i] = dst_pack(info.z, k, b.x) | (pm ? DST_PM : 0ull) | (b.y == t.stride ? DST_FULL : 0ull) |
                            ((info.y & META_OVF) ? DST_OVF : 0ull);
             if (pm && !(info.y & META_PMD)) atomicOr(&t.slots[s].meta, META_PMD);
             if (G > 0) {
-                const uint32_t k = class_of(info.x);
                 row_off = (uint64_t)info.z * 64 + slab_payload_off(k) + (uint64_t)b.x * t.stride;
                 row_len = b.y;
                 if (pm) slab_posmeta(t, info.z, k)[b.x] = make_uint2(b.y, b.z);
@@ -399,8 +401,8 @@ join_resolve_kernel(Table t, Work w, uint32_t n, uint64_t now, int32_t* status) 
                 ++m;
             }
         }
-        if (cur != 0) {
-            is_complex = true;
+        if (cur != 0 || (info.y & META_KX_MASK)) {
+            is_complex = true;      // a long chain, or a barrier whose count went back (only the wave kernel replays those)
         } else {
             mid = m > CHAIN_REG;
             ReplayState r;
@@ -525,6 +527,7 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
     uint32_t* ci = reinterpret_cast<uint32_t*>(cbuf + CHAIN_LDS);           // event indices
     uint32_t* scan_q = reinterpret_cast<uint32_t*>(cbuf);                   // the same 3 KB as a queue of 768 indices
     __shared__ uint32_t s_len;
+    __shared__ uint16_t kx_order[CHAIN_LDS];
     const uint32_t lane = threadIdx.x;
     const uint32_t nc = w.counters[C_COMPLEX];
     uint32_t n_mid = 0;        // chains the wide register replay would have taken (lane 0 counts)
@@ -534,7 +537,7 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
         for (uint32_t k = blockIdx.x; k < nre; k += gridDim.x) {
             const uint32_t ev = (uint32_t)w.dst[k];
             const Slot* sl = &t.slots[w.ev_slot[ev]];
-            const uint32_t kcls = class_of(sl->count), slab = sl->slab;
+            const uint32_t kcls = slab_class(sl->count, sl->meta), slab = sl->slab;
             const uint4 b = reinterpret_cast<const uint4*>(recs)[2 * (size_t)ev + 1];     // position, len, max_wait
             const uint4* from = reinterpret_cast<const uint4*>(payloads + (uint64_t)ev * pitch);
             uint4* to = reinterpret_cast<uint4*>(slab_payload(t, slab, kcls) + (uint64_t)b.x * t.stride);
@@ -547,7 +550,9 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
         if (w.cx_on && c < CX_CAP && w.cx_off[c] != IDX_NONE) continue;       // the parallel kernels have it
         const uint32_t s = w.complex_[c];
         Slot* sl = &t.slots[s];
-        const uint32_t count = sl->count, slab = sl->slab;
+        const uint32_t count = sl->count, slab = sl->slab, meta0 = sl->meta;
+        const uint32_t kcls = slab_class(count, meta0);
+        const bool wide = class_has_bitmap(kcls);
         const uint32_t head = sl->chain;
         for (uint32_t p = lane; p < count; p += 64) { fmin[p] = IDX_NONE; fmax[p] = 0; }    // count <= 999
         __syncthreads();
@@ -589,21 +594,85 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
             }
             __syncthreads();
         }
+        if (meta0 & META_KX_MASK) {
+            // The barrier holds messages beyond its count (a failed publish wrote an older, smaller count back): HLEN
+            // can pass the count and come back, so there is no single first COMPLETE index.  Lane 0 replays the events
+            // one by one in array order, as core/join would (core.clj:44-58).
+            const uint32_t len = s_len;
+            if (!scan && len <= CHAIN_LDS) {
+                // order of the chain's entries by event index: entry k has as many entries before it as are smaller
+                for (uint32_t k = lane; k < len; k += 64) {
+                    uint32_t r = 0;
+                    for (uint32_t j = 0; j < len; ++j) r += ci[j] < ci[k] ? 1u : 0u;
+                    kx_order[r] = (uint16_t)k;
+                }
+            }
+            __syncthreads();
+            uint64_t bits1 = sl->bits, pa = q_primary_at(t.q[s]);
+            uint32_t arrived = wide ? (uint32_t)bits1 : (uint32_t)__popcll(bits1);
+            bool enq = false, dirty = false;
+            auto step = [&](uint64_t x, uint32_t i) {           // lane 0 only
+                const uint32_t pos = node_pos(x), mw = node_mw(x);
+                if (wide) {
+                    uint64_t* bm = slab_bitmap(t, slab);
+                    const uint64_t word = bm[pos >> 6], bit = 1ull << (pos & 63);
+                    if (!(word & bit)) { bm[pos >> 6] = word | bit; ++arrived; }
+                } else {
+                    const uint64_t bit = 1ull << pos;
+                    if (!(bits1 & bit)) { bits1 |= bit; ++arrived; }
+                }
+                int32_t st = DJ_JOIN_WAITING;
+                if (arrived == count) {                          // all-there?, then queued at now (core.clj:52-54)
+                    st = DJ_JOIN_COMPLETE;
+                    enq = true;
+                    pa = now;
+                } else if (mw) {                                 // join-with-max-wait (core.clj:40-42, redis.clj:262-275)
+                    if (pa == NQ) st = DJ_JOIN_NEAREST_NOT_QUEUED;
+                    else if (pa > now + 1000ull * mw) { pa = now + 1000ull * mw; dirty = true; }
+                }
+                if (st != DJ_JOIN_WAITING) status[i] = st;
+                if (!w.fused && fmax[pos] != i + 1) w.dst[i] = NODST;
+            };
+            if (!scan && len <= CHAIN_LDS) {
+                if (lane == 0)
+                    for (uint32_t r = 0; r < len; ++r) step(cn[kx_order[r]], ci[kx_order[r]]);
+            } else {
+                // a chain too long for that: the batch in order, 64 events at a time (slow, and as rare as a replay
+                // storm on a barrier in this state)
+                for (uint64_t base = 0; base < n; base += 64) {
+                    const uint64_t i = base + lane;
+                    uint64_t m = __ballot(i < n && w.ev_slot[i] == s);
+                    while (m) {
+                        const int b = __ffsll((unsigned long long)m) - 1;
+                        m &= m - 1;
+                        if (lane == 0) step(w.node[base + b], (uint32_t)(base + b));
+                    }
+                }
+            }
+            if (lane == 0) {
+                sl->bits = wide ? (uint64_t)arrived : bits1;
+                sl->join_ts = now;
+                sl->chain = 0;
+                if (enq) { t.q[s] = now; ready_append_one(t, s, blockIdx.x); }
+                else if (dirty) { t.q[s] = pa; note_queue_date(t, pa); }
+            }
+        }
+        const bool plain = !(meta0 & META_KX_MASK);
         // newly present positions: 64 positions (one bitmap word) per step, one lane per position
         uint32_t t_complete = 0, n_new = 0;
-        const uint32_t words = (count + 63) >> 6;
+        const uint32_t words = plain ? (count + 63) >> 6 : 0;          // (the replay above has done all of this otherwise)
         const uint64_t bits_pre = sl->bits;
         uint64_t bits0 = bits_pre;
         for (uint32_t wd = 0; wd < words; ++wd) {
             const uint32_t p = wd * 64 + lane;
-            const uint64_t word = count > 64 ? slab_bitmap(t, slab)[wd] : bits_pre;
+            const uint64_t word = wide ? slab_bitmap(t, slab)[wd] : bits_pre;
             const uint32_t f = p < count ? fmin[p] : IDX_NONE;
             const bool fresh = f != IDX_NONE && !((word >> lane) & 1);
             if (fresh && f > t_complete) t_complete = f;
             const uint64_t add = __ballot(fresh);
             n_new += (uint32_t)__popcll(add);          // the same in every lane
             if (add) {
-                if (count > 64) { if (lane == 0) slab_bitmap(t, slab)[wd] = word | add; }
+                if (wide) { if (lane == 0) slab_bitmap(t, slab)[wd] = word | add; }
                 else bits0 = word | add;
             }
         }
@@ -611,7 +680,7 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
             const uint32_t o = __shfl_xor(t_complete, off);
             if (o > t_complete) t_complete = o;
         }
-        const uint32_t arrived_pre = count > 64 ? (uint32_t)bits_pre : (uint32_t)__popcll(bits_pre);
+        const uint32_t arrived_pre = wide ? (uint32_t)bits_pre : (uint32_t)__popcll(bits_pre);
         const uint32_t arrived = arrived_pre + n_new;
         // first event index that answers COMPLETE
         uint32_t T = IDX_NONE;
@@ -631,7 +700,8 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
             if (!w.fused && fmax[pos] != i + 1) w.dst[i] = NODST;
             return at;
         };
-        if (scan) {                               // all lanes, over the batch once more
+        if (!plain) {
+        } else if (scan) {                        // all lanes, over the batch once more
             for_events_of_slot(w, n, s, lane, scan_q, [&](uint64_t i) {
                 const uint64_t at = answer(w.node[i], (uint32_t)i);
                 if (at < at_min) at_min = at;
@@ -656,7 +726,6 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
         if (w.fused) {
             // every event has copied its message already, in no order: a position that several events of the batch
             // wrote gets its last writer's message again (HSET: the last write stays), by the whole wave
-            const uint32_t kcls = class_of(count);
             const bool stored = (sl->meta & META_PMD) != 0;
             for (uint32_t p = 0; p < count; ++p) {
                 const uint32_t last = fmax[p];
@@ -669,8 +738,8 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
                 if (lane == 0 && (stored || b.y != t.stride || b.z != 0)) slab_posmeta(t, slab, kcls)[p] = make_uint2(b.y, b.z);
             }
         }
-        if (lane == 0) {
-            sl->bits = count > 64 ? (uint64_t)arrived : bits0;
+        if (lane == 0 && plain) {
+            sl->bits = wide ? (uint64_t)arrived : bits0;
             sl->join_ts = now;
             sl->chain = 0;
             if (T != IDX_NONE) { t.q[s] = now; ready_append_one(t, s, blockIdx.x); }
@@ -713,11 +782,14 @@ __global__ void __launch_bounds__(256) cx_init_kernel(Table t, Work w) {
         const uint32_t c = c0 + tid;
         const bool has = tid < CX_BPB && c < nc;
         uint32_t count = 0, slab = 0, hot = 0;
+        bool serial_only = false;                  // a barrier whose count went back: replayed event by event, see the wave kernel
         if (has) {
             const Slot* sl = &t.slots[w.complex_[c]];
             count = sl->count;
             slab = sl->slab;                       // unique per barrier, never 0 for a joinable barrier
             hot = (sl->meta & META_HOT) ? 1u : 0u;
+            serial_only = (sl->meta & META_KX_MASK) != 0;
+            if (serial_only) count = 0;            // no share of the pool
         }
         // a barrier already known to be hot spreads its positions over one 64-byte line each: thousands
         // of atomics on ONE line would queue up
@@ -732,7 +804,7 @@ __global__ void __launch_bounds__(256) cx_init_kernel(Table t, Work w) {
             uint32_t off = IDX_NONE;
             if (has) {
                 off = base + incl - share;
-                if (off > CX_POOL - share) off = IDX_NONE;          // pool exhausted: left to the serial kernel
+                if (serial_only || off > CX_POOL - share) off = IDX_NONE;          // (or pool exhausted:) left to the serial kernel
                 w.cx_off[c] = off;
                 if (off != IDX_NONE) {
                     w.cx_atmin[c] = NQ;
@@ -1302,15 +1374,16 @@ __device__ inline void gather_body(const Table& t, const Work& w, const dj_cont*
         if (head.y & (DJ_CONT_NO_METADATA | CONT_VOID)) continue;
         const uint64_t pos_base = conts[kc].pos_base;
         Slot* sl = &t.slots[s];
-        const uint32_t count = head.x, slab = sl->slab, k = class_of(count);
-        const bool stored_meta = (sl->meta & META_PMD) != 0;    // else every present position is a full row, no max-wait
+        const uint32_t count = head.x, slab = sl->slab, smeta = sl->meta, k = slab_class(count, smeta);
+        const bool bitmap = class_has_bitmap(k);
+        const bool stored_meta = (smeta & META_PMD) != 0;    // else every present position is a full row, no max-wait
         const uint64_t bits0 = sl->bits;
         if (update_ts && j == 0) sl->join_ts_read = sl->join_ts;
         const uint64_t* bm = slab_bitmap(t, slab);
         const uint2* pm = slab_posmeta(t, slab, k);
         const uint8_t* pay = slab_payload(t, slab, k);
         for (uint32_t p = j; p < count; p += GS) {
-            const bool present = count > 64 ? ((bm[p >> 6] >> (p & 63)) & 1) : ((bits0 >> p) & 1);
+            const bool present = bitmap ? ((bm[p >> 6] >> (p & 63)) & 1) : ((bits0 >> p) & 1);
             const uint2 meta = !present ? make_uint2(DJ_NIL, 0) : stored_meta ? pm[p] : make_uint2(t.stride, 0);
             if (lens) lens[pos_base + p] = meta.x;
             if (max_waits) max_waits[pos_base + p] = meta.y;
@@ -1320,7 +1393,7 @@ __device__ inline void gather_body(const Table& t, const Work& w, const dj_cont*
         const uint32_t items = count * CH;
         for (uint32_t it = j; it < items; it += GS) {
             const uint32_t p = it / CH, ch = it - p * CH;
-            const bool present = count > 64 ? ((bm[p >> 6] >> (p & 63)) & 1) : ((bits0 >> p) & 1);
+            const bool present = bitmap ? ((bm[p >> 6] >> (p & 63)) & 1) : ((bits0 >> p) & 1);
             if (!present) continue;
             const uint32_t len = stored_meta ? pm[p].x : t.stride;   // a long message leaves its 16-byte reference in the row
             // whole 64-byte lines of the caller's row are written (zeros behind the message), never a part of one
@@ -1370,7 +1443,7 @@ __device__ inline bool complete_decide(const Table& t, uint64_t s, uint64_t now)
     Slot* sl = &t.slots[s];
     if (sl->join_ts == sl->join_ts_read) return true;          // two nils compare equal
     // reset-publish: both retry counters dropped, :publish-retry-cnt 0, re-queued at now
-    sl->meta = meta_pack(sl->meta & META_HAS, 0, RETRY_NIL) | (sl->meta & (META_OVF | META_PMD));
+    sl->meta = meta_pack(sl->meta & META_HAS, 0, RETRY_NIL) | (sl->meta & META_KEEP);
     t.q[s] = now;
     note_queue_date(t, now);
     return false;
@@ -1389,7 +1462,7 @@ __device__ inline bool retries_left(const Table& t, uint64_t deadline, uint32_t 
 __device__ inline void retry_requeue(const Table& t, uint64_t s, bool timeout, uint32_t cnt, uint32_t rp, uint32_t rt,
                                      uint64_t now) {
     if (timeout) rt = cnt + 1; else rp = cnt + 1;
-    t.slots[s].meta = meta_pack(true, rp, rt) | (t.slots[s].meta & (META_OVF | META_PMD));
+    t.slots[s].meta = meta_pack(true, rp, rt) | (t.slots[s].meta & META_KEEP);
     t.q[s] = now;
     note_queue_date(t, now);
 }
@@ -1404,9 +1477,9 @@ __global__ void __launch_bounds__(ACK_BLOCK) ack_kernel(Table t, uint32_t n_max,
     if (blockIdx.x * blockDim.x >= n) return;          // the whole block is beyond the end
     // ---- phase A (per lane): decide -----------------------------------------------------------
     int32_t st = 0;
-    bool clear = false, free_old = false, alloc = false, write_back = false, timeout = false;
+    bool clear = false, free_old = false, alloc = false, carry = false, write_back = false, timeout = false;
     uint64_t s_u = 0;
-    uint32_t k_old = 0, old_slab = 0, k_new = 0, cnt = 0, rp = RETRY_NIL, rt = RETRY_NIL;
+    uint32_t k_old = 0, old_slab = 0, k_new = 0, kx_new = 0, cnt = 0, rp = RETRY_NIL, rt = RETRY_NIL;
     // long-message blocks to give back: positions [rel_from, rel_to) of slab rel_slab (class rel_k)
     const bool long_on = t.max_message > t.stride;
     bool rel = false;
@@ -1441,11 +1514,13 @@ __global__ void __launch_bounds__(ACK_BLOCK) ack_kernel(Table t, uint32_t n_max,
                 st = deleted_code;
                 clear = true;
                 s_u = (uint64_t)s;
+                const uint32_t m = t.slots[s].meta;
                 old_slab = t.slots[s].slab;
-                k_old = class_of(t.slots[s].count);
+                k_old = slab_class(t.slots[s].count, m);
                 free_old = old_slab != 0;
-                if (long_on && (t.slots[s].meta & META_OVF)) {
-                    rel = true; rel_slab = old_slab; rel_k = k_old; rel_from = 0; rel_to = t.slots[s].count;
+                if (long_on && (m & META_OVF)) {
+                    rel = true; rel_slab = old_slab; rel_k = k_old; rel_from = 0;
+                    rel_to = (m & META_KX_MASK) ? class_positions(k_old) : t.slots[s].count;
                 }
             } else {
                 st = DJ_ACK_REQUEUED_DIRTY;
@@ -1465,22 +1540,21 @@ __global__ void __launch_bounds__(ACK_BLOCK) ack_kernel(Table t, uint32_t n_max,
                 }
                 write_back = true;
                 k_new = class_of(c.count);
-                if (sl->count != c.count) {
-                    // the snapshot's :count differs from the live one (barrier re-forked or deleted while
-                    // its publish was in flight): positions at or beyond the new count are dropped
-                    if (sl->slab == 0 || class_of(sl->count) != k_new) {
+                // The snapshot's :count may differ from the live one (the barrier was re-forked or deleted while its
+                // publish was in flight).  SET writes the metadata only: the messages stay, HLEN keeps counting all
+                // of them, reads see those below the count written here.  The slab therefore keeps its class when
+                // that is large enough, and grows (everything stored moves over) when it is not.
+                if (sl->slab == 0) {
+                    alloc = true;
+                } else {
+                    const uint32_t k_live = slab_class(sl->count, sl->meta);
+                    if (k_new > k_live) {
                         old_slab = sl->slab;
-                        k_old = class_of(sl->count);
-                        free_old = old_slab != 0;
+                        k_old = k_live;
                         alloc = true;
-                        if (long_on && (sl->meta & META_OVF)) {
-                            rel = true; rel_slab = old_slab; rel_k = k_old; rel_from = 0; rel_to = sl->count;
-                        }
+                        carry = true;
                     } else {
-                        if (c.count <= 64) sl->bits &= c.count == 64 ? ~0ull : ((1ull << c.count) - 1);
-                        if (long_on && (sl->meta & META_OVF) && c.count < sl->count) {
-                            rel = true; rel_slab = sl->slab; rel_k = k_new; rel_from = c.count; rel_to = sl->count;
-                        }
+                        kx_new = k_live != k_new ? k_live + 1 : 0;
                     }
                 }
             }
@@ -1488,13 +1562,36 @@ __global__ void __launch_bounds__(ACK_BLOCK) ack_kernel(Table t, uint32_t n_max,
     }
     // ---- phase B (block- and wave-cooperative): slab traffic, one atomic per size class ---------
     if (long_on) wave_release_long_each(t, rel, rel_slab, rel_k, rel_from, rel_to);
-    block_slab_free(t, free_old, k_old, old_slab, lds);
     const uint32_t fresh = wave_slab_alloc(t, alloc, k_new);
+    if (carry && fresh == 0) carry = false;            // arena exhausted (engine limit): the barrier keeps slab and count
+    wave_carry_each(t, carry, old_slab, k_old, fresh, k_new);
+    block_slab_free(t, free_old || carry, k_old, old_slab, lds);
     // ---- phase C (per lane): finish ------------------------------------------------------------------
     if (clear) clear_slot(t, s_u);
     if (write_back) {
         Slot* sl = &t.slots[s_u];
-        if (alloc) {
+        bool set_count = true;
+        if (carry) {
+            // presence moves with the messages: a word becomes the first word of a bitmap, a bitmap a longer one
+            if (class_has_bitmap(k_new)) {
+                uint64_t* nb = slab_bitmap(t, fresh);
+                const uint32_t nw = class_positions(k_new) >> 6;
+                uint32_t have = 1;
+                if (class_has_bitmap(k_old)) {
+                    const uint64_t* ob = slab_bitmap(t, old_slab);
+                    have = class_positions(k_old) >> 6;
+                    for (uint32_t j = 0; j < have; ++j) nb[j] = ob[j];
+                } else {
+                    nb[0] = sl->bits;
+                    sl->bits = (uint64_t)__popcll(sl->bits);
+                }
+                for (uint32_t j = have; j < nw; ++j) nb[j] = 0;
+            }
+            sl->slab = fresh;
+        } else if (alloc && old_slab != 0) {
+            set_count = false;                         // the slab could not grow
+            kx_new = (sl->meta & META_KX_MASK) >> META_KX_SHIFT;
+        } else if (alloc) {
             sl->slab = fresh;
             sl->bits = 0;
             if (fresh) fill_posmeta_default(t, fresh, k_new);
@@ -1503,9 +1600,10 @@ __global__ void __launch_bounds__(ACK_BLOCK) ack_kernel(Table t, uint32_t n_max,
                 for (uint32_t j = 0; j < (class_positions(k_new) >> 6); ++j) bm[j] = 0;
             }
         }
-        sl->count = c.count;
+        if (set_count) sl->count = c.count;
         sl->deadline = c.deadline_ms;
         retry_requeue(t, s_u, timeout, cnt, rp, rt, now);                  // core.clj:151
+        sl->meta = (sl->meta & ~META_KX_MASK) | (kx_new << META_KX_SHIFT);
         st = DJ_ACK_RETRY;
     }
     if (live) status[i] = st;
@@ -1564,13 +1662,14 @@ __global__ void __launch_bounds__(RECOVER_BLOCK) recover_kernel(Table t, uint64_
                 st = deleted_code;
                 clear = true;
                 old_slab = sl.slab;
-                k_old = class_of(sl.count);
+                k_old = slab_class(sl.count, sl.meta);
             } else {
                 st = DJ_ACK_REQUEUED_DIRTY;
             }
         }
         if (t.max_message > t.stride)
-            wave_release_long_each(t, clear && (sl.meta & META_OVF) != 0, old_slab, k_old, 0, sl.count);
+            wave_release_long_each(t, clear && (sl.meta & META_OVF) != 0, old_slab, k_old, 0,
+                                   (sl.meta & META_KX_MASK) ? class_positions(k_old) : sl.count);
         block_slab_free(t, clear && old_slab != 0, k_old, old_slab, lds);
         if (clear) clear_slot(t, s);
         if (due) {

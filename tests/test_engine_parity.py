@@ -3,10 +3,10 @@
 Each op-log mixes forks (re-forks included), joins with duplicates inside one batch (last
 writer wins, redis.clj:135), joins with max-wait, unknown ids and out-of-range positions,
 sweeps at a moving virtual clock, acks with failures (retry counters, exhaustion), joins
-that land between a sweep and its ack (dirty complete, redis.clj:177-188), recover passes, and
-acks that name a barrier twice (continuations of two pops acked together).  Not generated, because the
-engine documents a different outcome there: a failed publish whose metadata snapshot carries another
-:count than the live barrier.
+that land between a sweep and its ack (dirty complete, redis.clj:177-188), recover passes,
+acks that name a barrier twice (continuations of two pops acked together), and failed publishes whose
+metadata snapshot carries another :count than the barrier has by then (re-forked meanwhile): the
+snapshot's count is written back over messages stored under the other one (core.clj:107-111).
 """
 import numpy as np
 import pytest
@@ -40,10 +40,12 @@ def make_pair(oracle_lib, ids, stride, max_count=999, capacity=None, arena=256 <
 
 
 def run_oplog(d, rng, n_barriers, counts, stride, rounds, batch, hot=None, var_len=False, unknown=0, on_round=None,
-              long_to=None):
-    """counts[b] is fixed per barrier index (a re-fork keeps it).  on_round(r) runs after round r
-    (continuations may be in flight at that moment).  long_to: longest accepted message when the
-    engine takes messages beyond its inline row (40 % of the messages are then longer than a row)."""
+              long_to=None, recount=None, fail_every=5):
+    """counts[b] is the count barrier b is forked with; a re-fork keeps it unless recount=(lo, hi) draws a new one
+    for every fork record (a failed publish that was in flight over such a re-fork then writes the older count
+    back, core.clj:107-111).  on_round(r) runs after round r (continuations may be in flight at that moment).
+    long_to: longest accepted message when the engine takes messages beyond its inline row (40 % of the messages
+    are then longer than a row).  One publish in fail_every fails."""
     now = T0
     forked = np.zeros(n_barriers, dtype=bool)
     version = 0
@@ -54,7 +56,12 @@ def run_oplog(d, rng, n_barriers, counts, stride, rounds, batch, hot=None, var_l
         nf = int(rng.integers(1, max(2, n_barriers // 3)))
         fb = rng.integers(0, n_barriers, nf)
         mw = rng.integers(1, 4, nf)
-        d.fork(fb, counts[fb], now + 1000 * mw)
+        if recount:
+            newc = rng.integers(recount[0], recount[1] + 1, nf)
+            d.fork(fb, newc, now + 1000 * mw)
+            counts[fb] = newc                     # of several records of a barrier the last stays, here as there
+        else:
+            d.fork(fb, counts[fb], now + 1000 * mw)
         forked[fb] = True
         for _ in range(int(rng.integers(1, 4))):
             now += int(rng.integers(0, 300))
@@ -89,7 +96,7 @@ def run_oplog(d, rng, n_barriers, counts, stride, rounds, batch, hot=None, var_l
                     ec2, oc2 = inflight.pop(0)
                     ec, oc = np.concatenate([ec, ec2]), np.concatenate([oc, oc2])
                 now += int(rng.integers(0, 50))
-                d.ack(ec, oc, lambda k: (k * 7 + r) % 5 != 0, now)
+                d.ack(ec, oc, lambda k: (k * 7 + r) % fail_every != 0, now)
         if rng.random() < 0.5:
             now += int(rng.integers(0, 3000))
             d.recover(now)
@@ -178,6 +185,20 @@ def test_many_hot_barriers_at_once(oracle_lib, hot_mode):
         run_oplog(d, rng, nb, counts, 64, rounds=6, batch=60000)
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("lo,hi,hot_mode", [(1, 12, -1), (1, 12, 4), (40, 90, -1), (2, 300, -1), (2, 300, 1), (55, 70, 4)])
+def test_failed_publish_writes_an_older_count_back(oracle_lib, lo, hi, hot_mode):
+    """Barriers are re-forked with another count while continuations of their earlier lives are in flight, and every
+    second publish fails: the write-back sets a count below or above the one the stored messages arrived under
+    (presence word and bitmap forms, slabs that have to grow)."""
+    rng = np.random.default_rng(100 + lo + hi + hot_mode)
+    nb = 60
+    counts = rng.integers(lo, hi + 1, nb)
+    ids = [f"rc-{lo}-{hi}-{i}" for i in range(nb)]
+    e, o, d = make_pair(oracle_lib, ids, 64, hot_mode=hot_mode)
+    run_oplog(d, rng, nb, counts, 64, rounds=40, batch=300, recount=(lo, hi), fail_every=2, hot=3 if hot_mode == 1 else None)
+    e.close()
 
 
 @pytest.mark.parametrize("hot_mode", [-1, 0, 1, 4])
