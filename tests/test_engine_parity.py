@@ -352,13 +352,15 @@ def test_damaged_checkpoint_is_refused_before_the_engine_is_touched(oracle_lib, 
         e.close()
 
 
-@pytest.mark.parametrize("hot_mode", [-1, 1])
-def test_messages_longer_than_a_row(oracle_lib, tmp_path, hot_mode):
+@pytest.mark.parametrize("hot_mode,recount", [(-1, None), (1, None), (-1, (1, 90))])
+def test_messages_longer_than_a_row(oracle_lib, tmp_path, hot_mode, recount):
     """Engine with 64-byte inline rows that accepts messages up to 2 KiB: 40 % of the messages take a
     block of their own.  Overwrites (same and other size class, long over short and back), re-forks,
     failed publishes with retries, drops, recover, and a save / restore into a new engine every
     fourth round.  At the end every barrier is completed and deleted: every arena unit ever handed out
-    must be back in a free list (nothing leaked, nothing freed twice)."""
+    must be back in a free list (nothing leaked, nothing freed twice).  With recount the barriers are re-forked with
+    other counts and every second publish fails: long messages then also sit at positions beyond a count that a
+    failed publish wrote back, and move with their barrier when its slab has to grow."""
     from distributed_join_amd.engine import Engine
     rng = np.random.default_rng(99)
     nb, stride, M = 250, 64, 2048
@@ -382,7 +384,8 @@ def test_messages_longer_than_a_row(oracle_lib, tmp_path, hot_mode):
         assert d.e.stats() == before
 
     # with the parallel long-chain kernels forced on, a third of the joins go to barrier 1 (count 130)
-    run_oplog(d, rng, nb, counts, stride, rounds=12, batch=400, long_to=M, on_round=swap, hot=1 if hot_mode == 1 else None)
+    run_oplog(d, rng, nb, counts, stride, rounds=12, batch=400, long_to=M, on_round=swap, hot=1 if hot_mode == 1 else None,
+              recount=recount, fail_every=2 if recount else 5)
     # wind down: fork everything again (resets what is left), complete every barrier, publish, ack
     now = T0 + 10_000_000
     d.fork(np.arange(nb), counts, np.full(nb, now + 50_000))
