@@ -527,7 +527,7 @@ extern "C" int dj_fork_batch(dj_engine* e, uint32_t n, const dj_fork_rec* d_recs
     e->fork_bank ^= 1;
     if (e->profiling) (void)hipEventRecord(e->ev_start[DJ_PROF_FORK_CLAIM], e->stream);
     fork_claim_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, d_recs, n, d_status);
-    fork_contest_kernel<<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, e->w, n);
+    fork_contest_kernel<<<grid_for(n, 256) < 512 ? grid_for(n, 256) : 512, 256, 0, e->stream>>>(e->t, e->w, n);
     if (e->profiling) { (void)hipEventRecord(e->ev_stop[DJ_PROF_FORK_CLAIM], e->stream); e->ev_used[DJ_PROF_FORK_CLAIM] = 1; }
     LAUNCH(e, DJ_PROF_FORK_APPLY, (fork_apply_kernel<<<grid_for(n, FORK_APPLY_BLOCK), FORK_APPLY_BLOCK, 0, e->stream>>>(e->t, e->w, d_recs, n, d_status)));
     HIP_TRY(e, hipGetLastError());

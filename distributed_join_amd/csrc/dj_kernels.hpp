@@ -49,11 +49,11 @@ __global__ void __launch_bounds__(256) fork_claim_kernel(Table t, Work w, const 
 // pass 1b, only in a contested batch: the records that made their slots enter the contest too (another record of
 // the batch may name the same barrier, before or after them).
 __global__ void __launch_bounds__(256) fork_contest_kernel(Table t, Work w, uint32_t n) {
-    if (*w.fork_contested == 0) return;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t so = w.slot_of[i];
-    if (so != 0xFFFFFFFFu && (so & SLOT_CREATED)) a_max(&t.slots[so & ~SLOT_CREATED].chain, i + 1);
+    if (*w.fork_contested == 0) return;        // the usual case: a few hundred blocks that leave at once
+    for (uint64_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t so = w.slot_of[i];
+        if (so != 0xFFFFFFFFu && (so & SLOT_CREATED)) a_max(&t.slots[so & ~SLOT_CREATED].chain, (uint32_t)i + 1);
+    }
 }
 
 // pass 2: the winning record of each slot resets the barrier.
