@@ -516,7 +516,7 @@ def main():
                     "unit": "GB/s", "frac": round(kernels[dom]["achieved_GBps"] / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "traffic_source": (None if traffic is None else
                                        "profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload "
-                                       "collected in an earlier run (" + str((traffic_detail or {}).get("collected", "round 1, profile set g")) +
+                                       "collected in an earlier run (" + str((traffic_detail or {}).get("collected", "unlabelled collection")) +
                                        "), average per launch; not measured in this run"),
                     "avg_launch_ms": kernels[dom]["avg_ms"],
                     "alg_bytes_per_launch": kernels[dom]["alg_bytes_per_launch"], "traffic_detail": traffic_detail}

@@ -329,7 +329,8 @@ __device__ inline int64_t find_slot(const Table& t, uint64_t lo, uint64_t hi, ui
 
 // Lookup-or-insert for kernels that create slots (fork, retry write-back, orphan queue
 // entries).  Slots only go EMPTY/TOMB -> key inside such a kernel, so a key once seen is final.
-// Returns the slot or -1 when the table is full; *created says whether this call claimed it.
+// Returns the slot or -1 when the table is full (or a half-written slot never completed); *created says whether
+// this call claimed it.
 __device__ inline int64_t find_or_claim(const Table& t, uint64_t lo, uint64_t hi, bool* created) {
     *created = false;
     for (int attempt = 0; attempt < 64; ++attempt) {
@@ -349,6 +350,9 @@ __device__ inline int64_t find_or_claim(const Table& t, uint64_t lo, uint64_t hi
                     khi = a_load(&sl->fp_hi);
                 }
                 if (khi == hi) return (int64_t)s;
+                // Still half-written after ~30 ms: its claimer is not making progress.  The slot may yet turn out to be
+                // this key, so going on (and inserting the key a second time) would be worse than giving up.
+                if (khi == 0) return -1;
                 continue;  // another key with the same low half
             }
             if (klo == FP_TOMB) {
