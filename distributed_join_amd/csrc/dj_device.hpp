@@ -41,11 +41,13 @@ constexpr uint32_t META_PMD = 8u;      // some position holds (or held) a messag
                                        // max-wait: the per-position {len, max_wait} words are authoritative.  Without the
                                        // flag every present position is {payload_stride, 0}; the words (pre-filled with
                                        // that value at fork) are then neither written by joins nor read by gathers
-// Bits 4..7 of meta: size class of the barrier's slab + 1 where that is not class_of(count), else 0.  Only a failed
-// publish can make them differ: it writes its metadata snapshot back (redis.clj:106-111) and the snapshot's :count may
-// be older than the barrier (re-forked with another :count meanwhile).  The messages stored under the other count stay
-// where they are, are counted by HLEN as before and are invisible to reads beyond the new :count, so the slab keeps
-// (or grows to) the larger class and the presence word or bitmap keeps covering all its positions.
+// Bits 4..7 of meta: 0, or size class of the barrier's slab + 1 on a barrier that may hold messages at or beyond its
+// count.  Only a failed publish can bring that about: it writes its metadata snapshot back (redis.clj:106-111) and the
+// snapshot's :count may be older, and smaller, than the barrier's (re-forked with another :count meanwhile).  The
+// messages stored under the other count stay where they are, are counted by HLEN as before and are invisible to reads
+// beyond the new count, so the slab keeps its class (or grows, when a count is written back that it cannot hold) and
+// the presence word or bitmap keeps covering all its positions.  While the bits are set, HLEN can pass the count and
+// come back: the join kernels replay such a barrier event by event.
 constexpr uint32_t META_KX_SHIFT = 4;
 constexpr uint32_t META_KX_MASK = 0xFu << META_KX_SHIFT;
 constexpr uint32_t META_KEEP = META_OVF | META_PMD | META_KX_MASK;     // what a rewrite of the retry counters leaves alone

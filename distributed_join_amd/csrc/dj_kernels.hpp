@@ -1554,7 +1554,11 @@ __global__ void __launch_bounds__(ACK_BLOCK) ack_kernel(Table t, uint32_t n_max,
                         alloc = true;
                         carry = true;
                     } else {
-                        kx_new = k_live != k_new ? k_live + 1 : 0;
+                        // messages at or beyond the count written back may now exist (the count went down), or already
+                        // did: the barrier is marked, and replayed event by event from here on, also when its slab's
+                        // class happens to be that of the new count
+                        const bool marked = (sl->meta & META_KX_MASK) != 0;
+                        kx_new = (marked || c.count < sl->count || k_live != k_new) ? k_live + 1 : 0;
                     }
                 }
             }

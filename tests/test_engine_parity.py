@@ -187,17 +187,56 @@ def test_many_hot_barriers_at_once(oracle_lib, hot_mode):
         e.close()
 
 
-@pytest.mark.parametrize("lo,hi,hot_mode", [(1, 12, -1), (1, 12, 4), (40, 90, -1), (2, 300, -1), (2, 300, 1), (55, 70, 4)])
+@pytest.mark.parametrize("lo,hi,hot_mode", [(1, 12, -1), (1, 12, 4), (5, 8, -1), (40, 90, -1), (2, 300, -1), (2, 300, 1), (55, 70, 4)])
 def test_failed_publish_writes_an_older_count_back(oracle_lib, lo, hi, hot_mode):
     """Barriers are re-forked with another count while continuations of their earlier lives are in flight, and every
     second publish fails: the write-back sets a count below or above the one the stored messages arrived under
-    (presence word and bitmap forms, slabs that have to grow)."""
+    (presence word and bitmap forms, slabs that have to grow; counts 5..8 share one slab size, so there the count
+    goes down and up over stored messages without the slab ever changing)."""
     rng = np.random.default_rng(100 + lo + hi + hot_mode)
     nb = 60
     counts = rng.integers(lo, hi + 1, nb)
     ids = [f"rc-{lo}-{hi}-{i}" for i in range(nb)]
     e, o, d = make_pair(oracle_lib, ids, 64, hot_mode=hot_mode)
     run_oplog(d, rng, nb, counts, 64, rounds=40, batch=300, recount=(lo, hi), fail_every=2, hot=3 if hot_mode == 1 else None)
+    e.close()
+
+
+@pytest.mark.parametrize("hot_mode", [-1, 0, 4])
+def test_count_written_back_below_stored_messages_same_slab_size(oracle_lib, hot_mode):
+    """core.clj:107-111 step by step.  A barrier forked with count 5 times out and its publish is in flight; it is
+    forked again with count 8 and gets positions 5 and 6; the publish fails and writes count 5 back (same slab size:
+    8 positions), then the barrier is popped again.  Redis now holds 2 fields that reads no longer show, and HLEN
+    counts them: of a batch with positions 0, 1, 2, 3 the third event answers COMPLETE (HLEN 5 = count), the fourth
+    makes HLEN 6 and waits again, and its max-wait finds the barrier queued by the third."""
+    ids = ["back~1", "other~1"]
+    e, o, d = make_pair(oracle_lib, ids, 64, hot_mode=hot_mode, delay=2000)
+    now = T0
+    d.fork([0], [5], [now + 1000])
+    now += 1500                                       # past the deadline
+    ec1, oc1 = d.sweep(now)                           # the timeout publish of count 5, in flight
+    assert len(oc1) == 1
+    d.fork([0], [8], [now + 60_000])
+    pay = payload_bytes(np.array([0, 0]), np.array([5, 6]), np.array([1, 2]), 64)
+    assert d.join([0, 0], [5, 6], [64, 64], [0, 0], pay, now).tolist() == [capi.DJ_JOIN_WAITING] * 2
+    now += 10
+    assert list(d.ack(ec1, oc1, lambda k: False, now).values()) == [capi.DJ_ACK_RETRY]     # count 5 is back, queued at now
+    ec2, oc2 = d.sweep(now)                           # popped again: in no primary queue
+    assert len(oc2) == 1 and int(oc2[0]["count"]) == 5
+    now += 10
+    pay = payload_bytes(np.zeros(4, np.int64), np.arange(4), np.arange(4) + 10, 64)
+    st = d.join([0, 0, 0, 0], [0, 1, 2, 3], [64] * 4, [0, 0, 0, 1], pay, now)
+    assert st.tolist() == [capi.DJ_JOIN_WAITING, capi.DJ_JOIN_WAITING, capi.DJ_JOIN_COMPLETE, capi.DJ_JOIN_WAITING]
+    # a position at or beyond the count is refused although its message is still stored
+    assert d.join([0], [5], [64], [0], pay[:1], now).tolist() == [capi.DJ_JOIN_BAD_POSITION]
+    ec3, oc3 = d.sweep(now)                           # queued at now by the third event: 5 positions, 4 of them present
+    assert len(oc3) == 1
+    d.ack(ec2, oc2, lambda k: True, now)              # the publish of the second pop succeeds, but joins came after
+    d.ack(ec3, oc3, lambda k: True, now)              # it was read (dirty complete, redis.clj:177-188)
+    now += 5000
+    ec4, oc4 = d.sweep(now)
+    d.ack(ec4, oc4, lambda k: True, now)
+    d.check_all_snapshots()
     e.close()
 
 
