@@ -519,6 +519,10 @@ def main():
                                        "collected in an earlier run (" + str((traffic_detail or {}).get("collected", "unlabelled collection")) +
                                        "), average per launch; not measured in this run"),
                     "avg_launch_ms": kernels[dom]["avg_ms"],
+                    # what the memory actually moved for this kernel (counter bytes of the earlier collection over this
+                    # run's launch time): bytes the algorithm does not need count here, so this is load on the HBM, not credit
+                    "traffic_GBps": None if traffic is None else round(traffic / (kernels[dom]["avg_ms"] * 1e-3) / 1e9, 1),
+                    "traffic_frac_of_peak": None if traffic is None else round(traffic / (kernels[dom]["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                     "alg_bytes_per_launch": kernels[dom]["alg_bytes_per_launch"], "traffic_detail": traffic_detail}
         # measured streaming ceiling of this GPU beside the spec peak: device-to-device copy of 1 GiB
         src, dst = torch.empty(1 << 30, dtype=torch.uint8, device=dev), torch.empty(1 << 30, dtype=torch.uint8, device=dev)
