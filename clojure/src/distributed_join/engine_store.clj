@@ -101,7 +101,7 @@
   (delay (let [cfg (doto (Memory. 16)                                  ; struct dj_batcher_config
                      (.setInt 0 (int 16))
                      (.setInt 4 (int (or (:engine-batcher-max-batch env) 65536)))
-                     (.setInt 8 (int (or (:engine-batcher-linger-us env) 100)))
+                     (.setInt 8 (int (or (:engine-batcher-linger-us env) 0)))
                      (.setInt 12 (int max-message-bytes)))
                ref (PointerByReference.)]
            (check (native-int dj "dj_batcher_create" @engine cfg ref) "dj_batcher_create")

@@ -3,6 +3,7 @@
 //   T producer threads; each owns barriers of count C and sends fork, then C joins of P bytes.
 //   async mode: producers never wait for answers (a completion counter ends the run);
 //   sync mode:  every request waits for its answer (one request in flight per thread).
+//   usage: batcher_bench [threads [barriers per thread [mode [linger_us]]]]
 //   open mode (2): all forks first, then every thread streams its joins without waiting: the rate
 //                  the staging path itself sustains (mutex + copy into pinned memory + H2D + kernels).
 // Build (from the repo root):
@@ -31,6 +32,7 @@ int main(int argc, char** argv) {
     const int T = argc > 1 ? atoi(argv[1]) : 8;
     const uint32_t per_thread = argc > 2 ? (uint32_t)atoi(argv[2]) : 20000;   // barriers per thread
     const int sync_mode = argc > 3 ? atoi(argv[3]) : 0;
+    const uint32_t linger_us = argc > 4 ? (uint32_t)atoi(argv[4]) : 100;      // 0: a window closes as soon as the drain thread is free
     const uint32_t C = 8, P = 64;
     dj_config ec;
     memset(&ec, 0, sizeof ec);
@@ -45,7 +47,7 @@ int main(int argc, char** argv) {
     ec.max_retry_timeout_publish = 3;
     dj_engine* e = nullptr;
     if (dj_create(&ec, &e) != DJ_OK) { fprintf(stderr, "create: %s\n", dj_last_error(nullptr)); return 1; }
-    dj_batcher_config bc = {sizeof bc, 1u << 16, 100, P};
+    dj_batcher_config bc = {sizeof bc, 1u << 16, linger_us, P};
     dj_batcher* b = nullptr;
     if (dj_batcher_create(e, &bc, &b) != DJ_OK) { fprintf(stderr, "batcher create failed\n"); return 1; }
 
@@ -123,9 +125,9 @@ int main(int argc, char** argv) {
     dj_batcher_stats s;
     dj_batcher_get_stats(b, &s);
     const uint64_t timed = sync_mode == 2 ? (uint64_t)T * per_thread * C : total;
-    printf("threads %d mode %s: %llu requests in %.3f s = %.3f M requests/s (joins %.3f M/s); batches %llu, avg %.0f, largest %llu; "
+    printf("threads %d linger %u us mode %s: %llu requests in %.3f s = %.3f M requests/s (joins %.3f M/s); batches %llu, avg %.0f, largest %llu; "
            "complete %llu (want %llu), unexpected %llu\n",
-           T, sync_mode == 2 ? "open (joins only timed)" : sync_mode ? "sync" : "async-joins", (unsigned long long)timed, dt, timed / dt / 1e6,
+           T, linger_us, sync_mode == 2 ? "open (joins only timed)" : sync_mode ? "sync" : "async-joins", (unsigned long long)timed, dt, timed / dt / 1e6,
            (double)T * per_thread * C / dt / 1e6, (unsigned long long)s.batches,
            s.batches ? (double)(s.forks + s.joins) / s.batches : 0.0, (unsigned long long)s.largest_batch,
            (unsigned long long)g_complete.load(), (unsigned long long)T * per_thread, (unsigned long long)g_bad.load());
