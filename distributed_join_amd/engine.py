@@ -278,7 +278,8 @@ class Engine:
 
     def set_hot_path(self, mode):
         """-1 automatic, 0 serial, 1 parallel kernels for barriers with long chains; +2 pins the 16-event
-        register replay of short chains, 0 / 1 the 8-event one (same results in every mode)."""
+        register replay of short chains, 0 / 1 the 8-event one; +4 keeps the separate message-copy pass where
+        the link pass could copy the messages itself (same results in every mode)."""
         self._check(self.L.dj_set_hot_path(self.h, int(mode)))
 
     def set_sweep_path(self, mode):
