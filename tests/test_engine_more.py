@@ -1062,3 +1062,44 @@ def test_fork_batches_with_and_without_contested_barriers():
     check(ids4[pick], counts4[pick])
     assert e.stats()["live"] == 20000 + 6000 + 1000 + 2000
     e.close()
+
+
+@pytest.mark.gpu
+def test_fork_winner_at_a_million_records():
+    """One fork batch of 2^20 records over 600 000 barriers, 200 000 of which are live from an earlier batch and many
+    named twice or more inside the batch, each record with a count of its own: the last record of a barrier decides
+    (redis.clj:97-103).  Checked for every barrier through the positions a join batch accepts: count - 1 is taken,
+    count is refused."""
+    from distributed_join_amd import capi
+    from distributed_join_amd.engine import FORK_REC, JOIN_REC
+    nb, n = 600_000, 1 << 20
+    e = _engine(capacity_barriers=nb, arena_bytes=3 << 30, max_count=64, payload_stride=64, max_batch=n)
+    rng = np.random.default_rng(77)
+    fp = capi.fingerprint_many([f"w{b:x}~t" for b in range(nb)])
+
+    def fork(bidx, counts):
+        r = np.zeros(len(bidx), dtype=FORK_REC)
+        r["fp_lo"], r["fp_hi"] = fp[bidx, 0], fp[bidx, 1]
+        r["count"] = counts
+        r["deadline_ms"] = 1_700_000_000_000 + 3_600_000
+        st = e.fork_batch(r)
+        assert (st == capi.DJ_FORK_CREATED).all()
+
+    old = np.arange(200_000)
+    fork(old, rng.integers(1, 65, len(old)))
+    # every barrier at least once, the rest of the 2^20 records are repeats
+    bidx = np.concatenate([np.arange(nb), rng.integers(0, nb, n - nb)])
+    rng.shuffle(bidx)
+    counts = rng.integers(1, 65, n).astype(np.uint32)
+    fork(bidx, counts)
+    final = np.zeros(nb, np.uint32)
+    final[bidx] = counts                      # numpy keeps the last assignment of a repeated index, as the engine must
+    for pos, want in ((final - 1, (capi.DJ_JOIN_WAITING, capi.DJ_JOIN_COMPLETE)), (final, (capi.DJ_JOIN_BAD_POSITION,))):
+        j = np.zeros(nb, dtype=JOIN_REC)
+        j["fp_lo"], j["fp_hi"] = fp[:, 0], fp[:, 1]
+        j["position"], j["len"] = pos, 64
+        st = e.join_batch(j, np.zeros((nb, 64), np.uint8), 1_700_000_000_000)
+        bad = np.nonzero(~np.isin(st, want))[0]
+        assert len(bad) == 0, (bad[:10], st[bad[:10]], final[bad[:10]])
+    assert e.stats()["live"] == nb
+    e.close()
