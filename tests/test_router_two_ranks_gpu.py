@@ -1,11 +1,11 @@
-"""The N>1 path with two PROCESSES that each drive an engine on the GPU (both on device 0: the box
+"""The N>1 path with two (and eight) PROCESSES that each drive an engine on the GPU (all on device 0: the box
 has one): every rank routes its event stream with the Router (HIP partition kernels, dj_partition_joins; the
 buckets cross ranks with the planned all-to-all-v over gloo, staged through host memory here because
 two ranks of one RCCL communicator cannot share a device), and each rank applies what it owns.  One
 barrier receives as many events again as all the others together, so its owner takes its rows in several
 rounds (the receive buffers hold MAX_RECV rows).  The union of what the two engines fire, and what the hot
 barrier holds, must be what the oracle has after the whole stream in the router's global order (rank 0's
-events, then rank 1's)."""
+events, then rank 1's, ...)."""
 import os
 import sys
 
@@ -14,14 +14,19 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-WORLD = 2
-NB, C, P = 3000, 6, 64
+C, P = 6, 64
 T0 = 1_700_000_000_000
-HOT = WORLD * NB      # the hot barrier's index (positions 0..C-2 only: it never completes)
 MAX_RECV = 8192
 
 
-def gen_stream(rank):
+def shape(world):
+    """-> (barriers per rank, index of the hot barrier: positions 0..C-2 only, it never completes)"""
+    nb = 3000 if world <= 2 else 1000
+    return nb, world * nb
+
+
+def gen_stream(rank, world):
+    NB, HOT = shape(world)
     rng = np.random.default_rng(500 + rank)
     ev = rng.permutation(NB * C)
     ev = np.concatenate([ev, ev[rng.integers(0, NB * C, 300)]])      # replays: last writer wins
@@ -34,7 +39,9 @@ def gen_stream(rank):
     return b, pos, payload_bytes(b, pos, np.arange(len(b)) + 11 * rank, P)
 
 
-def worker(rank, port, out_dir):
+def worker(rank, world, port, out_dir):
+    WORLD = world
+    NB, HOT = shape(world)
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -80,7 +87,7 @@ def worker(rank, port, out_dir):
         assert (d_st[:n * 4].view(torch.int32) == capi.DJ_FORK_CREATED).all()
 
     routed(frecs, None, apply_forks)
-    b, pos, pay = gen_stream(rank)
+    b, pos, pay = gen_stream(rank, world)
     jrecs = np.zeros(len(b), dtype=capi.JOIN_REC)
     jrecs["fp_lo"], jrecs["fp_hi"], jrecs["position"], jrecs["len"] = fps[b, 0], fps[b, 1], pos, P
 
@@ -109,10 +116,13 @@ def worker(rank, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_engine_processes_fire_what_one_store_fires(tmp_path, oracle_lib):
+@pytest.mark.parametrize("WORLD", [2, 8])
+def test_engine_processes_fire_what_one_store_fires(tmp_path, oracle_lib, WORLD):
+    """Two ranks, and the eight of a full node (all on the one GPU of the box)."""
     import torch.multiprocessing as mp
-    port = 31500 + os.getpid() % 2000
-    mp.spawn(worker, args=(port, str(tmp_path)), nprocs=WORLD, join=True)
+    NB, HOT = shape(WORLD)
+    port = 31500 + os.getpid() % 2000 + WORLD
+    mp.spawn(worker, args=(WORLD, port, str(tmp_path)), nprocs=WORLD, join=True)
     fired = {}
     for r in range(WORLD):
         part = np.load(tmp_path / f"fired_{r}.npy", allow_pickle=True)[0]
@@ -123,7 +133,7 @@ def test_two_engine_processes_fire_what_one_store_fires(tmp_path, oracle_lib):
     o = oracle_lib.Oracle(ids, max_count=C, payload_stride=P)
     o.fork_batch(np.arange(WORLD * NB + 1), np.full(WORLD * NB + 1, C), np.full(WORLD * NB + 1, T0 + 3_600_000))
     for r in range(WORLD):
-        b, pos, pay = gen_stream(r)
+        b, pos, pay = gen_stream(r, WORLD)
         o.join_batch(b, pos, np.full(len(b), P), np.zeros(len(b)), pay, T0 + 5)
     _, hl, _, hp = o.snapshot_one(HOT)
     conts, lens, mws, payo = o.sweep(T0 + 10, cap_conts=1 << 14, cap_positions=1 << 17)
