@@ -1,0 +1,27 @@
+"""The router behind the C ABI (dj_router_*, csrc/dj_router.cpp) with several ranks.  RCCL refuses two ranks of one
+communicator on one device, so the ranks are threads of one program (tests/rccl_standin/router_ranks.cpp), each with an
+engine of its own on the GPU, connected by a stand-in for librccl (tests/rccl_standin/rccl_standin.cpp) that only that
+program's process gets to see (its directory is put on the dynamic linker's path for the child alone).  The router's
+own code runs unchanged: partition, all-gather of the bucket sizes, the plan, grouped sends and receives per round,
+buffer sets in flight.  A hot barrier makes its owner take every batch in several rounds."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DIR = os.path.join(ROOT, "tests", "rccl_standin")
+
+
+@pytest.mark.parametrize("ranks,n,max_recv,hot", [(2, 30000, 8192, 50), (4, 20000, 8192, 40), (8, 10000, 4096, 60), (3, 5000, 100000, 0)])
+def test_native_router_with_several_ranks(ranks, n, max_recv, hot):
+    exe, lib = os.path.join(DIR, "router_ranks"), os.path.join(DIR, "librccl.so.1")
+    assert os.path.exists(exe) and os.path.exists(lib), "run __graft_entry__.build() first"
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    p = subprocess.run([exe, str(ranks), str(n), str(max_recv), str(hot)], env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "every rank received its records in order" in p.stdout
+    rounds = int(p.stdout.split(":")[-1].split("rounds")[0])
+    assert (rounds > 1) == (hot > 0), p.stdout
