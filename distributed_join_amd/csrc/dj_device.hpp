@@ -144,6 +144,8 @@ struct Table {
     unsigned int* ready_n;            // [READY_SHARDS * READY_PAD] entries appended per shard (may run past the cap)
     unsigned int* ready_ovf;          // != 0: the list is incomplete, the next sweep scans
     unsigned long long* due_min;      // lower bound of the primary scores that are in no list (the bank the next sweep reads)
+    unsigned long long* qmin;         // the same bound per REGION of 64 consecutive slots (512 bytes of queue words): a scan
+                                      // reads 8 bytes per region and only the regions that can hold something due
     uint32_t ready_shard_cap;
     uint32_t ready_on;                // 0: no list and no bound are kept, every sweep scans (small tables: the scan is cheap
                                       // and hands the gather pass its barriers in slot order)
@@ -167,6 +169,7 @@ struct Work {
                                          // another record of it); while zero every record owns a fresh slot and wins it
     unsigned int* fork_contested_next;   // the next fork batch's word, zeroed by this one
     uint32_t* cont_slot; // sweep: slot of continuation k
+    uint32_t* regions;   // sweep (engines with a ready list): the 64-slot regions of the table that may hold something due
     unsigned int* counters;       // C_* below, bank of the current join batch
     unsigned int* counters_next;  // the other bank: zeroed by the current batch for the next one
     unsigned int* hint;           // pinned HOST memory: [0] barriers with long chains, [1] longest chain of the latest
@@ -213,7 +216,7 @@ constexpr uint32_t CX_POOL = 1u << 24; // positions of all of them together (the
 constexpr uint32_t IDX_NONE = 0xFFFFFFFFu;
 // sweep scratch: S_CURSOR packs both output cursors so a block takes its output range with one
 // atomic: continuations in the low 31 bits, positions above (positions * 64 B <= arena <= 256 GiB)
-enum { S_CURSOR = 0, S_MORE = 1, S_SCANNED = 2, S_COUNT = 4 };
+enum { S_CURSOR = 0, S_MORE = 1, S_SCANNED = 2, S_REGIONS = 3, S_COUNT = 4 };    // S_REGIONS: entries of Work::regions
 constexpr int CURSOR_SHIFT = 31;
 constexpr unsigned long long CURSOR_CONT_MASK = (1ull << CURSOR_SHIFT) - 1;
 
@@ -263,8 +266,20 @@ __device__ inline uint32_t wave_append(unsigned int* counter, bool pred) {
 
 // A primary score written without a ready-list entry: keep the sweep's scan bound below it.  Most callers see
 // a bound that is already low enough and issue no atomic.
-__device__ inline void note_queue_date(const Table& t, uint64_t at) {
+// (A plain read of a bound can only be too high inside one launch, never too low: bounds go down between sweeps, and
+// only a sweep's scan raises them.  Too high costs an atomic that changes nothing.)
+constexpr uint32_t REGION_SHIFT = 6;
+__device__ inline void note_region_date(const Table& t, uint64_t s, uint64_t at) {
+    if (!t.ready_on) return;
+    unsigned long long* r = &t.qmin[s >> REGION_SHIFT];
+    if (at < *r) __hip_atomic_fetch_min(r, (unsigned long long)at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void note_global_date(const Table& t, uint64_t at) {
     if (t.ready_on && at < a_load(t.due_min)) __hip_atomic_fetch_min(t.due_min, (unsigned long long)at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void note_queue_date(const Table& t, uint64_t s, uint64_t at) {
+    note_region_date(t, s, at);
+    note_global_date(t, at);
 }
 
 // Append the slots of lanes with pred to the ready list: one atomic per wave, on the counter of the shard

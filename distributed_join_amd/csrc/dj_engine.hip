@@ -284,6 +284,8 @@ static int create_impl(dj_engine* e) {
     HIP_TRY(e, hipMemsetAsync(t.ready_ovf, 0, 4, e->stream));
     HIP_TRY(e, hipMemsetAsync(e->d_due, 0xFF, 2 * 8, e->stream));      // nothing queued: no bound
     t.due_min = e->d_due;
+    ALLOC(e, t.qmin, (slots >> REGION_SHIFT) * 8);
+    HIP_TRY(e, hipMemsetAsync(t.qmin, 0xFF, (slots >> REGION_SHIFT) * 8, e->stream));
     t.ready_on = slots >= READY_AUTO_SLOTS ? 1u : 0u;
 
     Work& w = e->w;
@@ -294,6 +296,7 @@ static int create_impl(dj_engine* e) {
     ALLOC(e, w.complex_, nb * 4);
     ALLOC(e, w.slot_of, nb * 4);
     ALLOC(e, w.cont_slot, (nb > slots ? nb : slots) * 4);
+    ALLOC(e, w.regions, (slots >> REGION_SHIFT) * 4);
     ALLOC(e, e->d_fork_contested, 2 * 4);
     HIP_TRY(e, hipMemsetAsync(e->d_fork_contested, 0, 2 * 4, e->stream));
     ALLOC(e, e->d_counters, 2 * C_COUNT * 4);
@@ -710,11 +713,15 @@ static int sweep_impl(dj_engine* e, const char* what, uint64_t now_ms, uint32_t 
     e->w.due_next = e->t.due_min == e->d_due ? e->d_due + 1 : e->d_due;
     e->t.due_min = e->w.due_next;
     if (e->profiling) (void)hipEventRecord(e->ev_start[DJ_PROF_POP], e->stream);
-    // with a ready list: the drain, then the scan; on the device exactly one of them finds it is its turn
+    // with a ready list: the drain, then the two passes over the table's regions, which find on the device whether
+    // they have anything to do (a date that is not on the list has come) and then read only the regions with such a date
     if (e->t.ready_on) {
-        // (modest grids: the one whose turn it is not must get out of the way quickly)
+        // (modest grids: a kernel that has nothing to do must get out of the way quickly)
         pop_ready_kernel<<<READY_SHARDS * 4, 256, 0, e->stream>>>(e->t, e->w, now_ms, cap_conts, cap_positions, gather, d_conts);
-        pop_due_track_kernel<<<pop_blocks(e) > 1024 ? 1024 : pop_blocks(e), 256, 0, e->stream>>>(e->t, e->w, now_ms, cap_conts, cap_positions, gather, d_conts);
+        const uint64_t nreg = (e->t.mask + 1) >> REGION_SHIFT;
+        const uint64_t sel = (nreg + SELECT_BLOCK - 1) / SELECT_BLOCK;
+        select_regions_kernel<<<(uint32_t)(sel > 512 ? 512 : sel), SELECT_BLOCK, 0, e->stream>>>(e->t, e->w, now_ms);
+        pop_regions_kernel<<<pop_blocks(e) > 2048 ? 2048 : pop_blocks(e), 256, 0, e->stream>>>(e->t, e->w, now_ms, cap_conts, cap_positions, gather, d_conts);
     } else {
         pop_due_kernel<<<pop_blocks(e), 256, 0, e->stream>>>(e->t, e->w, now_ms, cap_conts, cap_positions, gather, d_conts);
     }

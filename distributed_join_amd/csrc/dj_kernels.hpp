@@ -128,6 +128,7 @@ __global__ void __launch_bounds__(FORK_APPLY_BLOCK) fork_apply_kernel(Table t, W
         sl->join_ts_read = 0;                                 // DEL <id>:join-ts-read
         sl->bits = 0;                                         // DEL <id>
         t.q[s] = r.deadline_ms;                               // ZREM both, then ZADD both (redis.clj:257-258)
+        note_region_date(t, s, r.deadline_ms);
     }
     // the sweep's scan bound must not be above any deadline queued here: one atomic per block at most
     unsigned long long lo = ok ? r.deadline_ms : NQ;
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(FORK_APPLY_BLOCK) fork_apply_kernel(Table t, W
     }
     if (t.ready_on && (threadIdx.x & 63) == 0 && lo != NQ) atomicMin(&due_lo, lo);
     __syncthreads();
-    if (threadIdx.x == 0 && due_lo != NQ) note_queue_date(t, due_lo);
+    if (threadIdx.x == 0 && due_lo != NQ) note_global_date(t, due_lo);
 }
 
 // =====================================================================================
@@ -446,7 +447,7 @@ join_resolve_kernel(Table t, Work w, uint32_t n, uint64_t now, int32_t* status) 
             sl->chain = 0;
             if (info.y & META_HOT) sl->meta = info.y & ~META_HOT; // a short chain: not hot any more
             if (r.enq) { t.q[s] = now; completed = true; }               // ZADD both at now, redis.clj:257-258
-            else if (r.pa_dirty) { t.q[s] = r.pa; note_queue_date(t, r.pa); }   // ZADD both at the nearer date, redis.clj:270-271
+            else if (r.pa_dirty) { t.q[s] = r.pa; note_queue_date(t, s, r.pa); }   // ZADD both at the nearer date, redis.clj:270-271
         }
     }
     ready_append_wave(t, completed, s, tid >> 6);
@@ -654,7 +655,7 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
                 sl->join_ts = now;
                 sl->chain = 0;
                 if (enq) { t.q[s] = now; ready_append_one(t, s, blockIdx.x); }
-                else if (dirty) { t.q[s] = pa; note_queue_date(t, pa); }
+                else if (dirty) { t.q[s] = pa; note_queue_date(t, s, pa); }
             }
         }
         const bool plain = !(meta0 & META_KX_MASK);
@@ -743,7 +744,7 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
             sl->join_ts = now;
             sl->chain = 0;
             if (T != IDX_NONE) { t.q[s] = now; ready_append_one(t, s, blockIdx.x); }
-            else if (pa_pre != NQ && at_min < pa_pre) { t.q[s] = at_min; note_queue_date(t, at_min); }
+            else if (pa_pre != NQ && at_min < pa_pre) { t.q[s] = at_min; note_queue_date(t, s, at_min); }
         }
         __syncthreads();
     }
@@ -960,7 +961,7 @@ __global__ void __launch_bounds__(64) cx_finalize_kernel(Table t, Work w, uint64
             sl->chain = 0;
             // events before T wait (store-nearest, redis.clj:269-271); from T on the barrier is queued at now
             if (T != IDX_NONE) { t.q[s] = now; ready_append_one(t, s, blockIdx.x); }
-            else if (pa_pre != NQ && at_min < pa_pre) { t.q[s] = at_min; note_queue_date(t, at_min); }
+            else if (pa_pre != NQ && at_min < pa_pre) { t.q[s] = at_min; note_queue_date(t, s, at_min); }
             const uint32_t events = w.cx_cnt[c];
             if (events > longest) longest = events;
             if (events <= CHAIN_REG_WIDE) ++n_mid;
@@ -1226,8 +1227,9 @@ __device__ inline void pop_emit_round(const Table& t, const Work& w, PopShared& 
         } else {
             w.sweep[S_MORE] = 1;
             if (popped) t.q[s] = pa;
-            // still due: the next sweep has to scan for it
+            // still due: the next sweep has to look for it (its region's bound may just have been raised past it)
             if (pa < a_load(w.due_next)) __hip_atomic_fetch_min(w.due_next, (unsigned long long)pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t.ready_on) __hip_atomic_fetch_min(&t.qmin[s >> REGION_SHIFT], (unsigned long long)pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
@@ -1238,7 +1240,7 @@ __global__ void __launch_bounds__(256) pop_ready_kernel(Table t, Work w, uint64_
                                                         uint64_t cap_pos, int alloc_pos, dj_cont* conts) {
     __shared__ PopShared sh;
     const uint32_t tid = threadIdx.x;
-    if (now >= *w.due_cur || *t.ready_ovf != 0) return;      // the scan's turn; nobody writes either word during a sweep's pop kernels
+    if (*t.ready_ovf != 0) return;      // the list is incomplete: every queue word is read instead (nobody writes this word during a sweep's pop kernels)
     // block b: shard b mod READY_SHARDS, every (gridDim.x / READY_SHARDS)-th piece of 256 entries of it
     const uint32_t shard = blockIdx.x & (READY_SHARDS - 1), per_shard = gridDim.x / READY_SHARDS;    // grid: a multiple of READY_SHARDS
     const uint32_t filled = t.ready_n[shard * READY_PAD];
@@ -1264,19 +1266,15 @@ __global__ void __launch_bounds__(256) pop_ready_kernel(Table t, Work w, uint64_
     }
 }
 
-// scan form; TRACK: the engine keeps a ready list, so the pass also has to recompute the scan bound
-template <bool TRACK>
+// scan form of engines without a ready list
 __device__ inline void pop_due_body(const Table& t, const Work& w, uint64_t now, uint32_t cap_conts,
                                                       uint64_t cap_pos, int alloc_pos, dj_cont* conts) {
     __shared__ uint16_t list[256 * POP_ITEMS];     // offsets of the chunk's due slots
     __shared__ uint32_t list_n;
     __shared__ PopShared sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
-    if (TRACK && now < *w.due_cur && *t.ready_ovf == 0) return;           // the ready list held everything that is due
-    if (TRACK && blockIdx.x == 0 && tid == 0) w.sweep[S_SCANNED] = 1;
     const uint64_t nslots = t.mask + 1;
     const uint64_t chunk = 256ull * POP_ITEMS;
-    uint64_t later = NQ;                             // smallest primary score beyond now that this thread saw
     for (uint64_t cb = blockIdx.x * chunk; cb < nslots; cb += (uint64_t)gridDim.x * chunk) {
         if (tid == 0) list_n = 0;
         __syncthreads();
@@ -1286,7 +1284,6 @@ __device__ inline void pop_due_body(const Table& t, const Work& w, uint64_t now,
             const uint64_t s = cb + (uint64_t)j * 256 + tid;
             const uint64_t qv = s < nslots ? t.q[s] : NQ;
             if (qv <= now) due_mask |= 1u << j;
-            else if (TRACK && qv < later) later = qv;     // popped and absent entries have bit 63 set: above every score
         }
         const uint32_t nd = (uint32_t)__popc(due_mask);
         const uint32_t incl = wave_incl_scan(nd);
@@ -1312,24 +1309,125 @@ __device__ inline void pop_due_body(const Table& t, const Work& w, uint64_t now,
             pop_emit_round(t, w, sh, has, s, pa, false, now, cap_conts, cap_pos, alloc_pos, conts);
         }
     }
-    if (!TRACK) return;                              // nobody reads the bound
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint64_t o = ((uint64_t)__shfl_xor((uint32_t)(later >> 32), off) << 32) | __shfl_xor((uint32_t)later, off);
-        if (o < later) later = o;
-    }
-    if (lane == 0 && !(later >> 63) && later < a_load(w.due_next))
-        __hip_atomic_fetch_min(w.due_next, (unsigned long long)later, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // (at most 80 scalar registers: from 82 on a compute unit admits seven blocks of 256 threads instead of eight)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8), amdgpu_num_sgpr(80)))
 pop_due_kernel(Table t, Work w, uint64_t now, uint32_t cap_conts, uint64_t cap_pos, int alloc_pos, dj_cont* conts) {
-    pop_due_body<false>(t, w, now, cap_conts, cap_pos, alloc_pos, conts);
+    pop_due_body(t, w, now, cap_conts, cap_pos, alloc_pos, conts);
 }
 
-__global__ void __launch_bounds__(256) pop_due_track_kernel(Table t, Work w, uint64_t now, uint32_t cap_conts,
-                                                            uint64_t cap_pos, int alloc_pos, dj_cont* conts) {
-    pop_due_body<true>(t, w, now, cap_conts, cap_pos, alloc_pos, conts);
+// ---- scan form for engines with a ready list: two passes over REGIONS of 64 slots -----------------------------
+// Every writer of a primary score that is not on the ready list keeps Table::qmin[slot / 64] at or below it.
+// Pass 1 reads the 8-byte bound of every region and lists the regions whose bound has been reached (all of them
+// after a list overflow, a compaction or a restore); pass 2 reads only the listed regions' queue words, pops what
+// is due and recomputes their bounds.  Cost: 8 bytes per region plus 512 bytes per region with something due,
+// where a plain scan reads every queue word.  Both leave at once while now has not reached the global bound.
+constexpr int SELECT_BLOCK = 1024;
+
+__global__ void __launch_bounds__(SELECT_BLOCK) select_regions_kernel(Table t, Work w, uint64_t now) {
+    __shared__ uint32_t n_blk, base_blk;
+    __shared__ unsigned long long later_blk;
+    const bool all = *t.ready_ovf != 0;
+    if (now < *w.due_cur && !all) return;            // the ready list holds everything that is due
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    if (blockIdx.x == 0 && tid == 0) w.sweep[S_SCANNED] = 1;
+    const uint64_t nreg = (t.mask + 1) >> REGION_SHIFT;
+    if (tid == 0) later_blk = NQ;
+    unsigned long long later = NQ;                   // smallest bound of the regions this thread leaves alone
+    for (uint64_t r0 = (uint64_t)blockIdx.x * SELECT_BLOCK; r0 < nreg; r0 += (uint64_t)gridDim.x * SELECT_BLOCK) {
+        if (tid == 0) n_blk = 0;
+        __syncthreads();
+        const uint64_t r = r0 + tid;
+        const unsigned long long qm = r < nreg ? t.qmin[r] : NQ;
+        const bool due = r < nreg && (all || qm <= now);
+        if (!due && qm < later) later = qm;
+        // a place in the block's part of the list: one LDS atomic per wave, one global atomic per block
+        const uint64_t m = __ballot(due);
+        uint32_t wbase = 0;
+        if (m && lane == 0) wbase = atomicAdd(&n_blk, (uint32_t)__popcll(m));
+        wbase = __shfl(wbase, 0);
+        __syncthreads();
+        if (tid == 0 && n_blk) base_blk = (uint32_t)a_add(&w.sweep[S_REGIONS], (unsigned long long)n_blk);
+        __syncthreads();
+        if (due) w.regions[base_blk + wbase + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = (uint32_t)r;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = ((unsigned long long)__shfl_xor((uint32_t)(later >> 32), off) << 32) | __shfl_xor((uint32_t)later, off);
+        if (o < later) later = o;
+    }
+    if (lane == 0 && later != NQ) atomicMin(&later_blk, later);
+    __syncthreads();
+    if (tid == 0 && later_blk < a_load(w.due_next))
+        __hip_atomic_fetch_min(w.due_next, later_blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// pass 2: a block works on 64 listed regions at a time (what pop_due_body calls a chunk: 256 threads x POP_ITEMS
+// queue words; wave wv reads region 4 j + wv of the 64 in step j), the regions' numbers in LDS
+__global__ void __launch_bounds__(256) pop_regions_kernel(Table t, Work w, uint64_t now, uint32_t cap_conts,
+                                                          uint64_t cap_pos, int alloc_pos, dj_cont* conts) {
+    __shared__ uint16_t list[256 * POP_ITEMS];
+    __shared__ uint32_t list_n;
+    __shared__ uint32_t reg[64];
+    __shared__ PopShared sh;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint64_t nr = w.sweep[S_REGIONS];          // 0 unless pass 1 found it was its turn
+    uint64_t later = NQ;
+    for (uint64_t c0 = (uint64_t)blockIdx.x * 64; c0 < nr; c0 += (uint64_t)gridDim.x * 64) {
+        if (tid == 0) list_n = 0;
+        if (tid < 64) reg[tid] = c0 + tid < nr ? w.regions[c0 + tid] : 0xFFFFFFFFu;
+        __syncthreads();
+        uint32_t due_mask = 0;
+        uint64_t qv[POP_ITEMS];
+#pragma unroll
+        for (int j = 0; j < POP_ITEMS; ++j) {
+            const uint32_t r = reg[j * 4 + wv];
+            qv[j] = r != 0xFFFFFFFFu ? t.q[((uint64_t)r << REGION_SHIFT) + lane] : NQ;
+        }
+#pragma unroll
+        for (int j = 0; j < POP_ITEMS; ++j) {
+            if (qv[j] <= now) due_mask |= 1u << j;
+            // the region's new bound: the smallest score beyond now that stays (popped and absent entries have bit 63
+            // set; what is due goes, or lowers the bound again where it does not fit the caller's buffers)
+            uint64_t m = (qv[j] > now && !(qv[j] >> 63)) ? qv[j] : NQ;
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint64_t o = ((uint64_t)__shfl_xor((uint32_t)(m >> 32), off) << 32) | __shfl_xor((uint32_t)m, off);
+                if (o < m) m = o;
+            }
+            const uint32_t r = reg[j * 4 + wv];
+            if (lane == 0 && r != 0xFFFFFFFFu) {
+                a_store(&t.qmin[r], (unsigned long long)m);
+                if (m < later) later = m;
+            }
+        }
+        const uint32_t nd = (uint32_t)__popc(due_mask);
+        const uint32_t incl = wave_incl_scan(nd);
+        const uint32_t wtot = __shfl(incl, 63);
+        if (wtot) {                                 // uniform across the wave
+            uint32_t wbase = 0;
+            if (lane == 63) wbase = atomicAdd(&list_n, wtot);
+            wbase = __shfl(wbase, 63);
+            uint32_t at = wbase + incl - nd;
+            for (uint32_t mk = due_mask; mk; mk &= mk - 1)
+                list[at++] = (uint16_t)((__ffs(mk) - 1) * 256 + tid);
+        }
+        __syncthreads();
+        const uint32_t ln = list_n;
+        for (uint32_t r = 0; r < ln; r += 256) {    // uniform across the block
+            const uint32_t e = r + tid;
+            const bool has = e < ln;
+            uint64_t s = 0, pa = 0;
+            if (has) {
+                const uint32_t code = list[e];      // step * 256 + thread
+                s = ((uint64_t)reg[(code >> 8) * 4 + ((code & 255) >> 6)] << REGION_SHIFT) + (code & 63);
+                pa = t.q[s];
+            }
+            pop_emit_round(t, w, sh, has, s, pa, false, now, cap_conts, cap_pos, alloc_pos, conts);
+        }
+        __syncthreads();                            // reg[] and list[] are rewritten by the next round of regions
+    }
+    if (later != NQ && later < a_load(w.due_next))   // lane 0 of each wave carries the regions' new bounds
+        __hip_atomic_fetch_min(w.due_next, (unsigned long long)later, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // clamp the raw cursors into the caller-visible result; resets the other sweep bank, hands the scan bound to
@@ -1346,6 +1444,7 @@ __device__ inline void publish_result(const Table& t, const Work& w, dj_sweep_re
     res->more = w.sweep[S_MORE] ? 1u : 0u;
     w.sweep_next[S_CURSOR] = 0;
     w.sweep_next[S_MORE] = 0;
+    w.sweep_next[S_REGIONS] = 0;
     if (!t.ready_on) return;
     w.sweep_next[S_SCANNED] = 0;
     // a scan has recomputed the bound into *due_next; a drain leaves what is queued for later where it was
@@ -1445,7 +1544,7 @@ __device__ inline bool complete_decide(const Table& t, uint64_t s, uint64_t now)
     // reset-publish: both retry counters dropped, :publish-retry-cnt 0, re-queued at now
     sl->meta = meta_pack(sl->meta & META_HAS, 0, RETRY_NIL) | (sl->meta & META_KEEP);
     t.q[s] = now;
-    note_queue_date(t, now);
+    note_queue_date(t, s, now);
     return false;
 }
 
@@ -1464,7 +1563,7 @@ __device__ inline void retry_requeue(const Table& t, uint64_t s, bool timeout, u
     if (timeout) rt = cnt + 1; else rp = cnt + 1;
     t.slots[s].meta = meta_pack(true, rp, rt) | (t.slots[s].meta & META_KEEP);
     t.q[s] = now;
-    note_queue_date(t, now);
+    note_queue_date(t, s, now);
 }
 
 constexpr int ACK_BLOCK = 1024;
@@ -1744,7 +1843,7 @@ __global__ void store_in_queue_one_kernel(Table t, uint64_t lo, uint64_t hi, uin
         sl->deadline = 0; sl->join_ts = 0; sl->join_ts_read = 0; sl->bits = 0;
     }
     t.q[s] = at;
-    note_queue_date(t, at);
+    note_queue_date(t, (uint64_t)s, at);
     *err = 0;
 }
 

@@ -96,7 +96,11 @@ def test_static_join_matches_join_batch_two_calls_in_a_row():
     # the hot barrier (count 64, never complete) position by position
     rm, rl, rw, rp = ref.snapshot_one(*fps[7])
     sm, sl, sw, sp = sta.snapshot_one(*fps[7])
-    assert rl.tobytes() == sl.tobytes() and rw.tobytes() == sw.tobytes() and rp.tobytes() == sp.tobytes()
+    assert rl.tobytes() == sl.tobytes() and rw.tobytes() == sw.tobytes()
+    # (a row's bytes beyond its message's length are not part of the answer: an empty message leaves its row alone)
+    for p in range(64):
+        k = 0 if int(rl[p]) == capi.DJ_NIL else int(rl[p])
+        assert bytes(rp[p][:k]) == bytes(sp[p][:k]), p
     ref.close()
     sta.close()
 
