@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """What a sweep costs on a large, mostly quiet table: capacity 16 M barriers (32 M slots, 256 MB of queue words),
 1 M live barriers, 64 K of them completed by each join batch.  Times the pop kernel (and gather, ack) with
-sweeps that scan the queue words and with sweeps that drain the ready list.
+sweeps that scan the queue words and with sweeps that drain the ready list; then the same table with barriers that
+time out instead (65 536 and 1024 per sweep, spread over the whole table).
 Usage: python tools/sweep_bench.py [log2 slots, default 25]"""
 import os
 import sys
@@ -64,6 +65,49 @@ def main():
         e.sweep_dev(T0 + 40 * 86_400_000, nb + 1024, (nb + 1024) * c, e.empty((nb + 1024) * 64), e.empty((nb + 1024) * c * 4), None,
                     e.empty((nb + 1024) * c * 64), res)
         e.sync()
+    # second scenario: nothing completes, barriers time out.  1 M live barriers whose deadlines are spread evenly over
+    # SPAN sweeps, so every sweep pops nb / SPAN of them from all over the table (and acks: they are then forked again
+    # with a deadline SPAN sweeps ahead, which keeps the table and the rate of expiry steady)
+    for span in (16, 1024):
+        for mode, name in ((0, "scan"), (1, "ready list + region bounds")):
+            e.set_sweep_path(mode)
+            now = T0 + 50 * 86_400_000 + (span * 1000 if mode else 0)
+            per = nb // span
+            order = torch.randperm(nb, device=dev)
+            forks[:, 3] = now + 1 + (torch.arange(nb, device=dev) // per)[torch.argsort(order)]
+            torch.cuda.synchronize()              # the engine's stream does not wait for torch's
+            e.fork_batch_dev(nb, forks, st)
+            e.sync()
+            acc = {}
+            cap = per + 1024
+            for r in range(12):
+                now += 1
+                if r >= 2:
+                    e.profile_enable(True)
+                e.sweep_dev(now, cap, cap * c, conts, lens, None, out, res)
+                e.ack_batch_dev(cap, res, conts, None, now, st)
+                e.sync()
+                if int(res[0]) != per:
+                    cc = conts.view(torch.int64).reshape(-1, 8)[:int(res[0])]
+                    print("  sweep", r, "popped", int(res[0]), "want", per, "deadline - now:", torch.unique(cc[:, 2] - now, return_counts=True))
+                    raise SystemExit(1)
+                if r >= 2:
+                    for k, v in e.profile_read().items():
+                        acc.setdefault(k, []).append(v)
+                    e.profile_enable(False)
+                # the same barriers again, due span sweeps from now
+                idx = (forks[:, 3] == now).nonzero().flatten()
+                again = forks[idx].clone()
+                again[:, 3] = now + span
+                forks[idx, 3] = now + span
+                torch.cuda.synchronize()
+                e.fork_batch_dev(len(idx), again, st)
+            print(f"{1 << lg} slots, {nb} live barriers, {per} time out per sweep, {name}: " +
+                  ", ".join(f"{k} {1e3 * sum(v) / len(v):.1f} us" for k, v in acc.items() if k in ("pop", "gather", "ack")))
+            e.sweep_dev(now + 40 * 86_400_000, nb + 1024, (nb + 1024) * c, e.empty((nb + 1024) * 64), e.empty((nb + 1024) * c * 4), None,
+                        e.empty((nb + 1024) * c * 64), res)
+            e.ack_batch_dev(nb + 1024, res, e.empty((nb + 1024) * 64), None, now, st)
+            e.sync()
     e.close()
 
 
