@@ -304,10 +304,11 @@ int dj_set_hot_path(dj_engine* e, int mode);
 
 /* How a sweep finds what is due.  The reference pops a sorted set by score (redis.clj:283-289), which costs
  * what is due, not what is stored.  The engine has two forms with identical results: a scan of the queue
- * words (8 bytes per table slot) and a ready list that join batches append completed barriers to, with a
- * lower bound of every other queue date that tells a sweep when a scan is needed after all (deadlines,
- * max-waits, re-queues).  mode -1: by table size (the list from 2^24 slots), 0: always scan, 1: keep the
- * list.  No reference counterpart. */
+ * words (8 bytes per table slot), and a ready list that join batches append completed barriers to, with lower
+ * bounds of every other queue date (deadlines, max-waits, re-queues): one for the table, which tells a sweep
+ * whether anything but the list can be due, and one per region of 64 slots, which tells it where (it then
+ * reads 8 bytes per region and the queue words of the regions that hold something due).  mode -1: by table
+ * size (the list from 2^24 slots), 0: always scan, 1: keep the list.  No reference counterpart. */
 int dj_set_sweep_path(dj_engine* e, int mode);
 
 /* ---- per-kernel timing (measurement aid; no counterpart in the reference) ---------- */
