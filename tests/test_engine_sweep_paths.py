@@ -125,3 +125,41 @@ def test_refork_and_compaction_between_completion_and_sweep(oracle_lib):
     d.ack(ec2, oc2, lambda k: True, T0 + 501)
     d.check_all_snapshots(range(0, n, 37))
     e.close()
+
+
+def test_dates_spread_over_a_large_sparse_table(oracle_lib, tmp_path):
+    """Deadlines, max-wait dates and re-queues in a table of 8192 regions of which most are empty: a sweep that reads
+    only the regions whose bound has been reached must still pop exactly what is due, after re-forks to earlier
+    deadlines, failed publishes (re-queued at now), a switch of the sweep form in mid-run, a compaction and a restore
+    from a checkpoint.  The op-log is the parity suite's; what differs is the table: 3000 barriers in 524 288 slots."""
+    from distributed_join_amd.engine import Engine
+    from tests import test_engine_parity as P
+    rng = np.random.default_rng(4242)
+    nb = 3000
+    ids = [f"sp{k:x}~t{k:x}" for k in range(nb)]
+    counts = rng.integers(1, 9, nb)
+    kw = dict(capacity_barriers=262_144, arena_bytes=64 << 20, max_count=999, payload_stride=64, max_batch=1 << 16,
+              check_publish_delay_ms=2000, host_cap_conts=1 << 16, host_cap_positions=1 << 20)
+    e = Engine(**kw)
+    e.set_sweep_path(MODE[0])
+    o = oracle_lib.Oracle(ids, max_count=999, payload_stride=64, check_publish_delay_ms=2000)
+    d = ParityDriver(e, o, ids)
+    path = tmp_path / "sparse.ckpt"
+
+    def between(r):
+        if r == 5:
+            d.e.set_sweep_path(0)                 # a few rounds with plain scans: nobody keeps the regions' bounds
+        if r == 8:
+            d.e.set_sweep_path(MODE[0])
+        if r == 11:
+            d.e.compact()
+        if r == 14:
+            d.e.checkpoint_save(path)
+            d.e.close()
+            d.e = Engine(**kw)
+            d.e.set_sweep_path(MODE[0])
+            d.e.checkpoint_load(path)
+
+    P.SWEEP_MODE[0] = MODE[0]
+    P.run_oplog(d, rng, nb, counts, 64, rounds=20, batch=1500, on_round=between, fail_every=3)
+    d.e.close()
