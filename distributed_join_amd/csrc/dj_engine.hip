@@ -127,8 +127,10 @@ static int dev_alloc(dj_engine* e, void** p, size_t bytes) {
 // Table size from which a sweep drains the ready list instead of scanning the queue words.  Below it the scan
 // costs less than the list does (measured at 2 M slots: the list's appends add 4 us to a join batch of 2^20
 // events, the pop is no faster, and the gather and ack passes lose 8 us because the continuations no longer
-// come in slot order); the scan grows with the table (8 bytes per slot), the list with what is due.
-constexpr uint64_t READY_AUTO_SLOTS = 1ull << 24;
+// come in slot order); the scan grows with the table (8 bytes per slot), the list with what is due.  Measured pop
+// step with 65 536 barriers due per sweep, scan against list: 4 M slots 22 / 19 us when they completed, 22 / 32 us
+// when they timed out; 8 M slots 36 / 16 and 36 / 40; 16 M slots 62 / 16 and 62 / 39.
+constexpr uint64_t READY_AUTO_SLOTS = 1ull << 23;
 
 static bool clock_ok(uint64_t now_ms) { return now_ms >= 1000000000000ull && now_ms < 9000000000000ull; }
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

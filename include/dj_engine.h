@@ -308,7 +308,7 @@ int dj_set_hot_path(dj_engine* e, int mode);
  * bounds of every other queue date (deadlines, max-waits, re-queues): one for the table, which tells a sweep
  * whether anything but the list can be due, and one per region of 64 slots, which tells it where (it then
  * reads 8 bytes per region and the queue words of the regions that hold something due).  mode -1: by table
- * size (the list from 2^24 slots), 0: always scan, 1: keep the list.  No reference counterpart. */
+ * size (the list from 2^23 slots), 0: always scan, 1: keep the list.  No reference counterpart. */
 int dj_set_sweep_path(dj_engine* e, int mode);
 
 /* ---- per-kernel timing (measurement aid; no counterpart in the reference) ---------- */
