@@ -331,8 +331,8 @@ static int create_impl(dj_engine* e) {
     ALLOC(e, e->d_one_payload, (size_t)c.max_count * c.payload_stride);
     ALLOC(e, e->d_one_err, 4);
     ALLOC(e, e->d_result, sizeof(dj_sweep_result));
-    ALLOC(e, e->d_part_counts, (size_t)grid_for(nb, PART_BLOCK) * PART_MAX_RANKS * 4);
-    ALLOC(e, e->d_part_counts2, (size_t)grid_for(nb, PART_BLOCK) * PART_MAX_RANKS * 4);
+    ALLOC(e, e->d_part_counts, (size_t)grid_for(nb, PART_TILE) * PART_MAX_RANKS * 4);
+    ALLOC(e, e->d_part_counts2, (size_t)grid_for(nb, PART_TILE) * PART_MAX_RANKS * 4);
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return DJ_OK;
 }
@@ -1128,7 +1128,7 @@ extern "C" int dj_partition_joins(dj_engine* e, uint32_t n, uint32_t n_ranks, co
         HIP_TRY(e, hipMemsetAsync(d_counts, 0, n_ranks * 4, st));
         return DJ_OK;
     }
-    const uint32_t blocks = grid_for(n, PART_BLOCK);
+    const uint32_t blocks = grid_for(n, PART_TILE);
     partition_count_kernel<<<blocks, PART_BLOCK, 0, st>>>(d_recs, n, n_ranks, scratch);
     partition_scan_kernel<<<1, 1024, 0, st>>>(scratch, blocks, n_ranks, d_counts);
     const uint64_t lanes = d_payloads ? pitch / 16 : 1;

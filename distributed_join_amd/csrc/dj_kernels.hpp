@@ -1882,101 +1882,203 @@ __host__ __device__ inline uint32_t owner_of(uint64_t lo, uint64_t hi, uint32_t 
 }
 
 constexpr int PART_BLOCK = 256;
+constexpr int PART_EPT = 4;                                  // events per thread
+constexpr int PART_TILE = PART_BLOCK * PART_EPT;             // events per block
+constexpr int PART_GROUPS = PART_EPT * (PART_BLOCK / 64);    // runs of 64 consecutive events per tile, one wave each
 constexpr int PART_MAX_RANKS = 64;
+constexpr uint32_t PART_NONE = 0xFFFFFFFFu;
 
-// counts[b * n_ranks + r] = events of block b owned by rank r
+// A tile is PART_TILE consecutive events; thread t of its block takes events tile0 + k * PART_BLOCK + t, k = 0..3, so
+// that a wave's loads are contiguous and group g = k * (waves per block) + wave covers events tile0 + 64 g .. + 63.
+
+// The lanes of a wave that hold the same owner, in lane order: -> this lane's rank among them; lane 0 leaves the
+// number of lanes per owner in row[owner] (LDS, zeroed by the caller: owners no lane holds are not written).
+__device__ inline uint32_t wave_rank_by_owner(uint32_t owner, uint32_t* row) {
+    const uint32_t lane = lane_id();
+    uint32_t rank_in = 0;
+    uint64_t todo = __ballot(owner != PART_NONE);
+    while (todo) {
+        const uint32_t r = __shfl(owner, __ffsll((unsigned long long)todo) - 1);
+        const uint64_t m = __ballot(owner == r);
+        if (owner == r) rank_in = (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        if (lane == 0) row[r] = (uint32_t)__popcll(m);
+        todo &= ~m;
+    }
+    return rank_in;
+}
+
+// block_counts[b * n_ranks + r] = events of tile b owned by rank r
 __global__ void __launch_bounds__(PART_BLOCK) partition_count_kernel(const dj_join_rec* recs, uint32_t n,
                                                                      uint32_t n_ranks, uint32_t* block_counts) {
     __shared__ uint32_t cnt[PART_MAX_RANKS];
     if (threadIdx.x < PART_MAX_RANKS) cnt[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t i = blockIdx.x * PART_BLOCK + threadIdx.x;
-    if (i < n) {
-        const ulonglong2 a = reinterpret_cast<const ulonglong2*>(recs)[2 * (size_t)i];
-        atomicAdd(&cnt[owner_of(a.x, a.y, n_ranks)], 1u);
+    const uint32_t tile0 = blockIdx.x * PART_TILE;
+    uint32_t owner[PART_EPT];
+#pragma unroll
+    for (int k = 0; k < PART_EPT; ++k) {
+        const uint32_t i = tile0 + k * PART_BLOCK + threadIdx.x;
+        owner[k] = i < n ? owner_of(0, reinterpret_cast<const uint64_t*>(recs)[4 * (size_t)i + 1], n_ranks) : PART_NONE;
+    }
+#pragma unroll
+    for (int k = 0; k < PART_EPT; ++k) {
+        uint64_t todo = __ballot(owner[k] != PART_NONE);
+        while (todo) {
+            const uint32_t r = __shfl(owner[k], __ffsll((unsigned long long)todo) - 1);
+            const uint64_t m = __ballot(owner[k] == r);
+            if (lane_id() == 0) atomicAdd(&cnt[r], (uint32_t)__popcll(m));
+            todo &= ~m;
+        }
     }
     __syncthreads();
     if (threadIdx.x < n_ranks) block_counts[blockIdx.x * n_ranks + threadIdx.x] = cnt[threadIdx.x];
 }
 
-// one block: exclusive scan in (rank, block) order; totals per rank to counts_out
+// One block: exclusive scan of the tile counts in (rank, tile) order, in place, so that block_counts[b * n_ranks + r]
+// becomes the output row of tile b's first event for rank r; totals per rank to counts_out.  Each thread takes `per`
+// consecutive elements; up to PART_SCAN_REG of them are held in registers between the two passes (one round trip to
+// memory instead of two chains of dependent loads).
+constexpr int PART_SCAN_REG = 8;
 __global__ void __launch_bounds__(1024) partition_scan_kernel(uint32_t* block_counts, uint32_t n_blocks,
                                                               uint32_t n_ranks, uint32_t* counts_out) {
-    __shared__ uint32_t part[1024];
-    __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t r = 0; r < n_ranks; ++r) {
-        const uint32_t start = carry;
-        for (uint32_t b0 = 0; b0 < n_blocks; b0 += 1024) {
-            const uint32_t b = b0 + threadIdx.x;
-            const uint32_t v = b < n_blocks ? block_counts[b * n_ranks + r] : 0;
-            part[threadIdx.x] = v;
-            __syncthreads();
-            for (uint32_t off = 1; off < 1024; off <<= 1) {
-                uint32_t x = threadIdx.x >= off ? part[threadIdx.x - off] : 0;
-                __syncthreads();
-                part[threadIdx.x] += x;
-                __syncthreads();
-            }
-            if (b < n_blocks) block_counts[b * n_ranks + r] = carry + part[threadIdx.x] - v;
-            __syncthreads();
-            if (threadIdx.x == 1023) carry += part[1023];
-            __syncthreads();
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t rank_start[PART_MAX_RANKS + 1];
+    const uint32_t total = n_blocks * n_ranks;                   // element e = r * n_blocks + b
+    const uint32_t per = (total + 1023) / 1024;
+    const uint32_t e0 = threadIdx.x * per < total ? threadIdx.x * per : total;
+    const uint32_t e1 = e0 + per < total ? e0 + per : total;
+    const uint32_t r0 = e0 / n_blocks, b0 = e0 - r0 * n_blocks;
+    const bool in_regs = per <= PART_SCAN_REG;
+    uint32_t held[PART_SCAN_REG];
+    uint32_t sum = 0;
+    if (in_regs) {
+        uint32_t r = r0, b = b0;
+#pragma unroll
+        for (int k = 0; k < PART_SCAN_REG; ++k) {
+            held[k] = e0 + k < e1 ? block_counts[b * n_ranks + r] : 0;
+            if (++b == n_blocks) { b = 0; ++r; }
         }
-        if (threadIdx.x == 0) counts_out[r] = carry - start;
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PART_SCAN_REG; ++k) sum += held[k];
+    } else {
+        uint32_t r = r0, b = b0;
+        for (uint32_t e = e0; e < e1; ++e) {
+            sum += block_counts[b * n_ranks + r];
+            if (++b == n_blocks) { b = 0; ++r; }
+        }
     }
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t incl = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t x = __shfl_up(incl, off);
+        if (lane >= (uint32_t)off) incl += x;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (uint32_t v = 0; v < wv; ++v) run += wave_tot[v];
+    {
+        uint32_t r = r0, b = b0;
+        if (in_regs) {
+#pragma unroll
+            for (int k = 0; k < PART_SCAN_REG; ++k) {
+                if (e0 + k < e1) {
+                    if (b == 0) rank_start[r] = run;
+                    block_counts[b * n_ranks + r] = run;
+                    run += held[k];
+                }
+                if (++b == n_blocks) { b = 0; ++r; }
+            }
+        } else {
+            for (uint32_t e = e0; e < e1; ++e) {
+                const uint32_t v = block_counts[b * n_ranks + r];
+                if (b == 0) rank_start[r] = run;
+                block_counts[b * n_ranks + r] = run;
+                run += v;
+                if (++b == n_blocks) { b = 0; ++r; }
+            }
+        }
+    }
+    if (threadIdx.x == 1023) rank_start[n_ranks] = run;          // the last thread ends at the grand total
+    __syncthreads();
+    if (threadIdx.x < n_ranks) counts_out[threadIdx.x] = rank_start[threadIdx.x + 1] - rank_start[threadIdx.x];
 }
 
 // scatter records (and the origin index) to their rank group, keeping array order inside a group;
 // the messages follow in the same pass (G lanes per row, 16 bytes per lane, destinations handed
-// from lane to lane inside the wave)
+// from lane to lane inside the wave, four rows per lane group in flight)
 template <int G>
 __global__ void __launch_bounds__(PART_BLOCK) partition_scatter_kernel(const dj_join_rec* recs, uint32_t n,
                                                                        uint32_t n_ranks, const uint32_t* block_offsets,
                                                                        dj_join_rec* recs_out, uint32_t* origin,
                                                                        const uint8_t* pay_in, uint8_t* pay_out,
                                                                        uint64_t pitch) {
-    __shared__ uint32_t wave_cnt[PART_BLOCK / 64][PART_MAX_RANKS];
+    __shared__ uint32_t cnt[PART_GROUPS][PART_MAX_RANKS];
+    for (uint32_t j = threadIdx.x; j < PART_GROUPS * PART_MAX_RANKS; j += PART_BLOCK) (&cnt[0][0])[j] = 0;
+    __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t i = blockIdx.x * PART_BLOCK + threadIdx.x;
-    uint32_t owner = 0xFFFFFFFFu;
-    ulonglong2 a, b;
-    if (i < n) {
-        a = reinterpret_cast<const ulonglong2*>(recs)[2 * (size_t)i];
-        b = reinterpret_cast<const ulonglong2*>(recs)[2 * (size_t)i + 1];
-        owner = owner_of(a.x, a.y, n_ranks);
+    const uint32_t tile0 = blockIdx.x * PART_TILE;
+    ulonglong2 a[PART_EPT], b[PART_EPT];
+    uint32_t owner[PART_EPT], o[PART_EPT];
+#pragma unroll
+    for (int k = 0; k < PART_EPT; ++k) {
+        const uint32_t i = tile0 + k * PART_BLOCK + threadIdx.x;
+        owner[k] = PART_NONE;
+        if (i < n) {
+            a[k] = reinterpret_cast<const ulonglong2*>(recs)[2 * (size_t)i];
+            b[k] = reinterpret_cast<const ulonglong2*>(recs)[2 * (size_t)i + 1];
+            owner[k] = owner_of(a[k].x, a[k].y, n_ranks);
+        }
     }
-    uint32_t rank_in_wave = 0;
-    for (uint32_t r = 0; r < n_ranks; ++r) {
-        const uint64_t m = __ballot(owner == r);
-        if (owner == r) rank_in_wave = (uint32_t)__popcll(m & ((1ull << lane) - 1));
-        if (lane == 0) wave_cnt[wv][r] = (uint32_t)__popcll(m);
+#pragma unroll
+    for (int k = 0; k < PART_EPT; ++k) o[k] = wave_rank_by_owner(owner[k], cnt[k * (PART_BLOCK / 64) + wv]);
+    __syncthreads();
+    if (threadIdx.x < n_ranks) {            // per rank: where each group's events start in the output
+        uint32_t run = block_offsets[blockIdx.x * n_ranks + threadIdx.x];
+        for (int g = 0; g < PART_GROUPS; ++g) {
+            const uint32_t v = cnt[g][threadIdx.x];
+            cnt[g][threadIdx.x] = run;
+            run += v;
+        }
     }
     __syncthreads();
-    uint32_t o = 0xFFFFFFFFu;
-    if (i < n) {
-        uint32_t before = 0;
-        for (uint32_t v = 0; v < wv; ++v) before += wave_cnt[v][owner];
-        o = block_offsets[blockIdx.x * n_ranks + owner] + before + rank_in_wave;
-        reinterpret_cast<ulonglong2*>(recs_out)[2 * (size_t)o] = a;
-        reinterpret_cast<ulonglong2*>(recs_out)[2 * (size_t)o + 1] = b;
-        origin[o] = i;
+#pragma unroll
+    for (int k = 0; k < PART_EPT; ++k) {
+        if (owner[k] == PART_NONE) { o[k] = PART_NONE; continue; }
+        o[k] += cnt[k * (PART_BLOCK / 64) + wv][owner[k]];
+        reinterpret_cast<ulonglong2*>(recs_out)[2 * (size_t)o[k]] = a[k];
+        reinterpret_cast<ulonglong2*>(recs_out)[2 * (size_t)o[k] + 1] = b[k];
+        origin[o[k]] = tile0 + k * PART_BLOCK + threadIdx.x;
     }
     if (pay_in == nullptr) return;
-    constexpr int RPW = 64 / G;
+    constexpr int RPW = 64 / G;                                  // rows a wave copies per step
+    constexpr int FLIGHT = 4;                                    // steps whose loads are issued before the first store
     const uint32_t sub = lane / G, j0 = lane % G;
     const uint32_t chunks = (uint32_t)(pitch >> 4);
-    const uint32_t wave_i0 = i - lane;
 #pragma unroll 1
-    for (int step = 0; step < G; ++step) {
-        const uint32_t src_lane = step * RPW + sub;
-        const uint32_t oo = __shfl(o, src_lane);
-        if (oo == 0xFFFFFFFFu) continue;
-        const uint4* src = reinterpret_cast<const uint4*>(pay_in + (uint64_t)(wave_i0 + src_lane) * pitch);
-        uint4* dstp = reinterpret_cast<uint4*>(pay_out + (uint64_t)oo * pitch);
-        for (uint32_t c = j0; c < chunks; c += G) nt_store(&dstp[c], nt_load(&src[c]));
+    for (int k = 0; k < PART_EPT; ++k) {
+        const uint32_t wave_i0 = tile0 + k * PART_BLOCK + wv * 64;
+        if (wave_i0 >= n) break;
+#pragma unroll 1
+        for (uint32_t c0 = 0; c0 < chunks; c0 += G) {
+            const uint32_t c = c0 + j0;
+#pragma unroll 1
+            for (int step0 = 0; step0 < G; step0 += FLIGHT) {
+                uint4 v[FLIGHT];
+                uint32_t oo[FLIGHT];
+#pragma unroll
+                for (int f = 0; f < FLIGHT; ++f) {
+                    const uint32_t src_lane = (step0 + f) * RPW + sub;
+                    oo[f] = __shfl(o[k], src_lane);
+                    if (c >= chunks) oo[f] = PART_NONE;
+                    if (oo[f] != PART_NONE)
+                        v[f] = nt_load(&reinterpret_cast<const uint4*>(pay_in + (uint64_t)(wave_i0 + src_lane) * pitch)[c]);
+                }
+#pragma unroll
+                for (int f = 0; f < FLIGHT; ++f)
+                    if (oo[f] != PART_NONE) nt_store(&reinterpret_cast<uint4*>(pay_out + (uint64_t)oo[f] * pitch)[c], v[f]);
+            }
+        }
     }
 }
 
