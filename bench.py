@@ -401,12 +401,15 @@ def main():
             # next batches' bucket sizes (the routing runs on the router's stream meanwhile).  Two batches
             # ahead: the exchange of batch k+1 was started a step ago, so the engine never waits for the
             # host.  The next job's forks are routed during the current job's last step.
+            # the batch after this one was started a step ago: its bucket sizes are in, its rows can cross now (queued
+            # before the next start, whose all-gather of sizes waits for its partition on the same stream)
+            if pending:
+                router.advance(pending[0])
             for ahead in range(1, prefetch + 1):
                 if len(pending) < ahead:
                     pending.append(start_route(k + len(pending) + 1))
-            # the batch after this one was started a step ago: its bucket sizes are in, its rows can cross now
             if pending:
-                router.advance(pending[0])
+                router.advance(pending[0])      # (already done unless the pipeline was empty)
             if prefetch and s == steps_per_job - 1 and not pending_fork:
                 pending_fork.append(router.start(fork_recs, None, nb))
         if a.hot_frac > 0 or a.zipf_frac > 0:

@@ -60,7 +60,7 @@ SYMBOLS = ["dj_create", "dj_destroy", "dj_last_error", "dj_sync", "dj_stream", "
            "dj_profile_read", "dj_compact", "dj_set_hot_path", "dj_checkpoint_save", "dj_checkpoint_load",
            "dj_get_config", "dj_fetch_long", "dj_join_batch_static",
            "dj_set_sweep_path", "dj_route_plan", "dj_route_unique_id", "dj_router_create", "dj_router_destroy",
-           "dj_router_last_error", "dj_route_start", "dj_route_next", "dj_route_release"]
+           "dj_router_last_error", "dj_route_start", "dj_route_advance", "dj_route_next", "dj_route_release"]
 # include/dj_batcher.h
 BATCHER_SYMBOLS = ["dj_batcher_create", "dj_batcher_destroy", "dj_batcher_set_clock", "dj_batcher_join",
                    "dj_batcher_fork", "dj_batcher_join_wait", "dj_batcher_fork_wait", "dj_batcher_run",
@@ -168,6 +168,8 @@ def load():
         L.dj_router_last_error.argtypes = [vp]
         L.dj_route_start.restype = i32
         L.dj_route_start.argtypes = [vp, u32, vp, vp, ctypes.POINTER(ctypes.c_int)]
+        L.dj_route_advance.restype = i32
+        L.dj_route_advance.argtypes = [vp, ctypes.c_int]
         L.dj_route_next.restype = i32
         L.dj_route_next.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(u32),
                                     ctypes.POINTER(ctypes.c_int)]

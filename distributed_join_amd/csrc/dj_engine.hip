@@ -52,7 +52,7 @@ struct dj_engine {
     uint8_t* d_one_payload;
     int32_t* d_one_err;
     dj_sweep_result* d_result;   // internal result block when the caller passes none
-    uint32_t* d_part_counts;     // partition scratch: blocks * ranks (engine stream)
+    uint32_t* d_part_counts;     // partition scratch: segments * ranks, at most 32768 words (engine stream)
     uint32_t* d_part_counts2;    // same, for partitions launched on a caller stream
     void* allocs[128];
     int n_allocs;
@@ -331,8 +331,8 @@ static int create_impl(dj_engine* e) {
     ALLOC(e, e->d_one_payload, (size_t)c.max_count * c.payload_stride);
     ALLOC(e, e->d_one_err, 4);
     ALLOC(e, e->d_result, sizeof(dj_sweep_result));
-    ALLOC(e, e->d_part_counts, (size_t)grid_for(nb, PART_TILE) * PART_MAX_RANKS * 4);
-    ALLOC(e, e->d_part_counts2, (size_t)grid_for(nb, PART_TILE) * PART_MAX_RANKS * 4);
+    ALLOC(e, e->d_part_counts, 32768 * 4);
+    ALLOC(e, e->d_part_counts2, 32768 * 4);
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     return DJ_OK;
 }
@@ -1128,11 +1128,15 @@ extern "C" int dj_partition_joins(dj_engine* e, uint32_t n, uint32_t n_ranks, co
         HIP_TRY(e, hipMemsetAsync(d_counts, 0, n_ranks * 4, st));
         return DJ_OK;
     }
-    const uint32_t blocks = grid_for(n, PART_TILE);
-    partition_count_kernel<<<blocks, PART_BLOCK, 0, st>>>(d_recs, n, n_ranks, scratch);
-    partition_scan_kernel<<<1, 1024, 0, st>>>(scratch, blocks, n_ranks, d_counts);
+    // at most 1024 segments and segments x ranks <= 32768: every scatter block adds the segment counts up itself
+    uint32_t seg_max = 32768 / n_ranks;
+    if (seg_max > 1024) seg_max = 1024;
+    const uint32_t tiles = grid_for(n, PART_TILE);
+    const uint32_t tiles_per_seg = (tiles + seg_max - 1) / seg_max;
+    const uint32_t segs = (tiles + tiles_per_seg - 1) / tiles_per_seg;
+    partition_count_kernel<<<segs, PART_BLOCK, 0, st>>>(d_recs, n, n_ranks, tiles_per_seg, scratch);
     const uint64_t lanes = d_payloads ? pitch / 16 : 1;
-#define DJ_SCATTER(G) partition_scatter_kernel<G><<<blocks, PART_BLOCK, 0, st>>>(d_recs, n, n_ranks, scratch, d_recs_out, d_origin, d_payloads, d_payloads_out, pitch)
+#define DJ_SCATTER(G) partition_scatter_kernel<G><<<segs, PART_BLOCK, 0, st>>>(d_recs, n, n_ranks, tiles_per_seg, scratch, d_counts, d_recs_out, d_origin, d_payloads, d_payloads_out, pitch)
     if (lanes <= 4) DJ_SCATTER(4);
     else if (lanes <= 8) DJ_SCATTER(8);
     else if (lanes <= 16) DJ_SCATTER(16);

@@ -1890,6 +1890,9 @@ constexpr uint32_t PART_NONE = 0xFFFFFFFFu;
 
 // A tile is PART_TILE consecutive events; thread t of its block takes events tile0 + k * PART_BLOCK + t, k = 0..3, so
 // that a wave's loads are contiguous and group g = k * (waves per block) + wave covers events tile0 + 64 g .. + 63.
+// Block s of either pass owns SEGMENT s: tiles s * tiles_per_seg .. + tiles_per_seg - 1.  The host keeps
+// segments at 1024 and segments x ranks at 32768 or less, so that every block of the scatter pass can add the segment
+// counts up itself (32 KB of reads that hit the L2 with eight ranks) and no pass of a single block stands between the two.
 
 // The lanes of a wave that hold the same owner, in lane order: -> this lane's rank among them; lane 0 leaves the
 // number of lanes per owner in row[owner] (LDS, zeroed by the caller: owners no lane holds are not written).
@@ -1907,176 +1910,139 @@ __device__ inline uint32_t wave_rank_by_owner(uint32_t owner, uint32_t* row) {
     return rank_in;
 }
 
-// block_counts[b * n_ranks + r] = events of tile b owned by rank r
-__global__ void __launch_bounds__(PART_BLOCK) partition_count_kernel(const dj_join_rec* recs, uint32_t n,
-                                                                     uint32_t n_ranks, uint32_t* block_counts) {
+// seg_counts[r * n_seg + s] = events of segment s owned by rank r
+__global__ void __launch_bounds__(PART_BLOCK) partition_count_kernel(const dj_join_rec* recs, uint32_t n, uint32_t n_ranks,
+                                                                     uint32_t tiles_per_seg, uint32_t* seg_counts) {
     __shared__ uint32_t cnt[PART_MAX_RANKS];
     if (threadIdx.x < PART_MAX_RANKS) cnt[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t tile0 = blockIdx.x * PART_TILE;
-    uint32_t owner[PART_EPT];
+    for (uint32_t tl = 0; tl < tiles_per_seg; ++tl) {
+        const uint64_t tile0 = ((uint64_t)blockIdx.x * tiles_per_seg + tl) * PART_TILE;
+        if (tile0 >= n) break;
+        uint32_t owner[PART_EPT];
 #pragma unroll
-    for (int k = 0; k < PART_EPT; ++k) {
-        const uint32_t i = tile0 + k * PART_BLOCK + threadIdx.x;
-        owner[k] = i < n ? owner_of(0, reinterpret_cast<const uint64_t*>(recs)[4 * (size_t)i + 1], n_ranks) : PART_NONE;
-    }
-#pragma unroll
-    for (int k = 0; k < PART_EPT; ++k) {
-        uint64_t todo = __ballot(owner[k] != PART_NONE);
-        while (todo) {
-            const uint32_t r = __shfl(owner[k], __ffsll((unsigned long long)todo) - 1);
-            const uint64_t m = __ballot(owner[k] == r);
-            if (lane_id() == 0) atomicAdd(&cnt[r], (uint32_t)__popcll(m));
-            todo &= ~m;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < n_ranks) block_counts[blockIdx.x * n_ranks + threadIdx.x] = cnt[threadIdx.x];
-}
-
-// One block: exclusive scan of the tile counts in (rank, tile) order, in place, so that block_counts[b * n_ranks + r]
-// becomes the output row of tile b's first event for rank r; totals per rank to counts_out.  Each thread takes `per`
-// consecutive elements; up to PART_SCAN_REG of them are held in registers between the two passes (one round trip to
-// memory instead of two chains of dependent loads).
-constexpr int PART_SCAN_REG = 8;
-__global__ void __launch_bounds__(1024) partition_scan_kernel(uint32_t* block_counts, uint32_t n_blocks,
-                                                              uint32_t n_ranks, uint32_t* counts_out) {
-    __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t rank_start[PART_MAX_RANKS + 1];
-    const uint32_t total = n_blocks * n_ranks;                   // element e = r * n_blocks + b
-    const uint32_t per = (total + 1023) / 1024;
-    const uint32_t e0 = threadIdx.x * per < total ? threadIdx.x * per : total;
-    const uint32_t e1 = e0 + per < total ? e0 + per : total;
-    const uint32_t r0 = e0 / n_blocks, b0 = e0 - r0 * n_blocks;
-    const bool in_regs = per <= PART_SCAN_REG;
-    uint32_t held[PART_SCAN_REG];
-    uint32_t sum = 0;
-    if (in_regs) {
-        uint32_t r = r0, b = b0;
-#pragma unroll
-        for (int k = 0; k < PART_SCAN_REG; ++k) {
-            held[k] = e0 + k < e1 ? block_counts[b * n_ranks + r] : 0;
-            if (++b == n_blocks) { b = 0; ++r; }
+        for (int k = 0; k < PART_EPT; ++k) {
+            const uint64_t i = tile0 + k * PART_BLOCK + threadIdx.x;
+            owner[k] = i < n ? owner_of(0, reinterpret_cast<const uint64_t*>(recs)[4 * i + 1], n_ranks) : PART_NONE;
         }
 #pragma unroll
-        for (int k = 0; k < PART_SCAN_REG; ++k) sum += held[k];
-    } else {
-        uint32_t r = r0, b = b0;
-        for (uint32_t e = e0; e < e1; ++e) {
-            sum += block_counts[b * n_ranks + r];
-            if (++b == n_blocks) { b = 0; ++r; }
-        }
-    }
-    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t incl = sum;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t x = __shfl_up(incl, off);
-        if (lane >= (uint32_t)off) incl += x;
-    }
-    if (lane == 63) wave_tot[wv] = incl;
-    __syncthreads();
-    uint32_t run = incl - sum;
-    for (uint32_t v = 0; v < wv; ++v) run += wave_tot[v];
-    {
-        uint32_t r = r0, b = b0;
-        if (in_regs) {
-#pragma unroll
-            for (int k = 0; k < PART_SCAN_REG; ++k) {
-                if (e0 + k < e1) {
-                    if (b == 0) rank_start[r] = run;
-                    block_counts[b * n_ranks + r] = run;
-                    run += held[k];
-                }
-                if (++b == n_blocks) { b = 0; ++r; }
-            }
-        } else {
-            for (uint32_t e = e0; e < e1; ++e) {
-                const uint32_t v = block_counts[b * n_ranks + r];
-                if (b == 0) rank_start[r] = run;
-                block_counts[b * n_ranks + r] = run;
-                run += v;
-                if (++b == n_blocks) { b = 0; ++r; }
+        for (int k = 0; k < PART_EPT; ++k) {
+            uint64_t todo = __ballot(owner[k] != PART_NONE);
+            while (todo) {
+                const uint32_t r = __shfl(owner[k], __ffsll((unsigned long long)todo) - 1);
+                const uint64_t m = __ballot(owner[k] == r);
+                if (lane_id() == 0) atomicAdd(&cnt[r], (uint32_t)__popcll(m));
+                todo &= ~m;
             }
         }
     }
-    if (threadIdx.x == 1023) rank_start[n_ranks] = run;          // the last thread ends at the grand total
     __syncthreads();
-    if (threadIdx.x < n_ranks) counts_out[threadIdx.x] = rank_start[threadIdx.x + 1] - rank_start[threadIdx.x];
+    if (threadIdx.x < n_ranks) seg_counts[threadIdx.x * gridDim.x + blockIdx.x] = cnt[threadIdx.x];
 }
 
 // scatter records (and the origin index) to their rank group, keeping array order inside a group;
 // the messages follow in the same pass (G lanes per row, 16 bytes per lane, destinations handed
-// from lane to lane inside the wave, four rows per lane group in flight)
+// from lane to lane inside the wave, four rows per lane group in flight).  Block 0 also writes the
+// totals per rank to counts_out.
 template <int G>
-__global__ void __launch_bounds__(PART_BLOCK) partition_scatter_kernel(const dj_join_rec* recs, uint32_t n,
-                                                                       uint32_t n_ranks, const uint32_t* block_offsets,
-                                                                       dj_join_rec* recs_out, uint32_t* origin,
-                                                                       const uint8_t* pay_in, uint8_t* pay_out,
-                                                                       uint64_t pitch) {
+__global__ void __launch_bounds__(PART_BLOCK) partition_scatter_kernel(const dj_join_rec* recs, uint32_t n, uint32_t n_ranks,
+                                                                       uint32_t tiles_per_seg, const uint32_t* seg_counts,
+                                                                       uint32_t* counts_out, dj_join_rec* recs_out,
+                                                                       uint32_t* origin, const uint8_t* pay_in,
+                                                                       uint8_t* pay_out, uint64_t pitch) {
     __shared__ uint32_t cnt[PART_GROUPS][PART_MAX_RANKS];
-    for (uint32_t j = threadIdx.x; j < PART_GROUPS * PART_MAX_RANKS; j += PART_BLOCK) (&cnt[0][0])[j] = 0;
-    __syncthreads();
+    __shared__ uint32_t tot[PART_MAX_RANKS], base[PART_MAX_RANKS];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const uint32_t tile0 = blockIdx.x * PART_TILE;
-    ulonglong2 a[PART_EPT], b[PART_EPT];
-    uint32_t owner[PART_EPT], o[PART_EPT];
-#pragma unroll
-    for (int k = 0; k < PART_EPT; ++k) {
-        const uint32_t i = tile0 + k * PART_BLOCK + threadIdx.x;
-        owner[k] = PART_NONE;
-        if (i < n) {
-            a[k] = reinterpret_cast<const ulonglong2*>(recs)[2 * (size_t)i];
-            b[k] = reinterpret_cast<const ulonglong2*>(recs)[2 * (size_t)i + 1];
-            owner[k] = owner_of(a[k].x, a[k].y, n_ranks);
+    const uint32_t n_seg = gridDim.x;
+    // where this segment's events start in each rank's group: the rank's events in earlier segments, behind
+    // everything of the ranks before it
+    for (uint32_t r = wv; r < n_ranks; r += PART_BLOCK / 64) {
+        uint32_t all = 0, before = 0;
+        for (uint32_t j = lane; j < n_seg; j += 64) {
+            const uint32_t v = seg_counts[r * n_seg + j];
+            all += v;
+            if (j < blockIdx.x) before += v;
         }
-    }
-#pragma unroll
-    for (int k = 0; k < PART_EPT; ++k) o[k] = wave_rank_by_owner(owner[k], cnt[k * (PART_BLOCK / 64) + wv]);
-    __syncthreads();
-    if (threadIdx.x < n_ranks) {            // per rank: where each group's events start in the output
-        uint32_t run = block_offsets[blockIdx.x * n_ranks + threadIdx.x];
-        for (int g = 0; g < PART_GROUPS; ++g) {
-            const uint32_t v = cnt[g][threadIdx.x];
-            cnt[g][threadIdx.x] = run;
-            run += v;
-        }
+        for (int off = 32; off > 0; off >>= 1) { all += __shfl_xor(all, off); before += __shfl_xor(before, off); }
+        if (lane == 0) { tot[r] = all; base[r] = before; }
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < PART_EPT; ++k) {
-        if (owner[k] == PART_NONE) { o[k] = PART_NONE; continue; }
-        o[k] += cnt[k * (PART_BLOCK / 64) + wv][owner[k]];
-        reinterpret_cast<ulonglong2*>(recs_out)[2 * (size_t)o[k]] = a[k];
-        reinterpret_cast<ulonglong2*>(recs_out)[2 * (size_t)o[k] + 1] = b[k];
-        origin[o[k]] = tile0 + k * PART_BLOCK + threadIdx.x;
+    uint32_t mine = 0;
+    if (threadIdx.x < n_ranks) {
+        mine = base[threadIdx.x];
+        for (uint32_t r = 0; r < threadIdx.x; ++r) mine += tot[r];
+        if (blockIdx.x == 0) counts_out[threadIdx.x] = tot[threadIdx.x];
     }
-    if (pay_in == nullptr) return;
+    __syncthreads();
+    if (threadIdx.x < n_ranks) base[threadIdx.x] = mine;
+
     constexpr int RPW = 64 / G;                                  // rows a wave copies per step
     constexpr int FLIGHT = 4;                                    // steps whose loads are issued before the first store
     const uint32_t sub = lane / G, j0 = lane % G;
     const uint32_t chunks = (uint32_t)(pitch >> 4);
-#pragma unroll 1
-    for (int k = 0; k < PART_EPT; ++k) {
-        const uint32_t wave_i0 = tile0 + k * PART_BLOCK + wv * 64;
-        if (wave_i0 >= n) break;
-#pragma unroll 1
-        for (uint32_t c0 = 0; c0 < chunks; c0 += G) {
-            const uint32_t c = c0 + j0;
-#pragma unroll 1
-            for (int step0 = 0; step0 < G; step0 += FLIGHT) {
-                uint4 v[FLIGHT];
-                uint32_t oo[FLIGHT];
+    for (uint32_t tl = 0; tl < tiles_per_seg; ++tl) {
+        const uint64_t tile0 = ((uint64_t)blockIdx.x * tiles_per_seg + tl) * PART_TILE;
+        if (tile0 >= n) break;                                   // uniform across the block
+        __syncthreads();                                         // the previous tile's offsets have been read
+        for (uint32_t j = threadIdx.x; j < PART_GROUPS * PART_MAX_RANKS; j += PART_BLOCK) (&cnt[0][0])[j] = 0;
+        __syncthreads();
+        ulonglong2 a[PART_EPT], b[PART_EPT];
+        uint32_t owner[PART_EPT], o[PART_EPT];
 #pragma unroll
-                for (int f = 0; f < FLIGHT; ++f) {
-                    const uint32_t src_lane = (step0 + f) * RPW + sub;
-                    oo[f] = __shfl(o[k], src_lane);
-                    if (c >= chunks) oo[f] = PART_NONE;
-                    if (oo[f] != PART_NONE)
-                        v[f] = nt_load(&reinterpret_cast<const uint4*>(pay_in + (uint64_t)(wave_i0 + src_lane) * pitch)[c]);
+        for (int k = 0; k < PART_EPT; ++k) {
+            const uint64_t i = tile0 + k * PART_BLOCK + threadIdx.x;
+            owner[k] = PART_NONE;
+            if (i < n) {
+                a[k] = reinterpret_cast<const ulonglong2*>(recs)[2 * i];
+                b[k] = reinterpret_cast<const ulonglong2*>(recs)[2 * i + 1];
+                owner[k] = owner_of(a[k].x, a[k].y, n_ranks);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PART_EPT; ++k) o[k] = wave_rank_by_owner(owner[k], cnt[k * (PART_BLOCK / 64) + wv]);
+        __syncthreads();
+        if (threadIdx.x < n_ranks) {            // per rank: where each group's events start in the output
+            uint32_t run = base[threadIdx.x];
+            for (int g = 0; g < PART_GROUPS; ++g) {
+                const uint32_t v = cnt[g][threadIdx.x];
+                cnt[g][threadIdx.x] = run;
+                run += v;
+            }
+            base[threadIdx.x] = run;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PART_EPT; ++k) {
+            if (owner[k] == PART_NONE) { o[k] = PART_NONE; continue; }
+            o[k] += cnt[k * (PART_BLOCK / 64) + wv][owner[k]];
+            reinterpret_cast<ulonglong2*>(recs_out)[2 * (size_t)o[k]] = a[k];
+            reinterpret_cast<ulonglong2*>(recs_out)[2 * (size_t)o[k] + 1] = b[k];
+            origin[o[k]] = (uint32_t)(tile0 + k * PART_BLOCK + threadIdx.x);
+        }
+        if (pay_in == nullptr) continue;
+#pragma unroll 1
+        for (int k = 0; k < PART_EPT; ++k) {
+            const uint64_t wave_i0 = tile0 + k * PART_BLOCK + wv * 64;
+            if (wave_i0 >= n) break;
+#pragma unroll 1
+            for (uint32_t c0 = 0; c0 < chunks; c0 += G) {
+                const uint32_t c = c0 + j0;
+#pragma unroll 1
+                for (int step0 = 0; step0 < G; step0 += FLIGHT) {
+                    uint4 v[FLIGHT];
+                    uint32_t oo[FLIGHT];
+#pragma unroll
+                    for (int f = 0; f < FLIGHT; ++f) {
+                        const uint32_t src_lane = (step0 + f) * RPW + sub;
+                        oo[f] = __shfl(o[k], src_lane);
+                        if (c >= chunks) oo[f] = PART_NONE;
+                        if (oo[f] != PART_NONE)
+                            v[f] = nt_load(&reinterpret_cast<const uint4*>(pay_in + (wave_i0 + src_lane) * pitch)[c]);
+                    }
+#pragma unroll
+                    for (int f = 0; f < FLIGHT; ++f)
+                        if (oo[f] != PART_NONE) nt_store(&reinterpret_cast<uint4*>(pay_out + (uint64_t)oo[f] * pitch)[c], v[f]);
                 }
-#pragma unroll
-                for (int f = 0; f < FLIGHT; ++f)
-                    if (oo[f] != PART_NONE) nt_store(&reinterpret_cast<uint4*>(pay_out + (uint64_t)oo[f] * pitch)[c], v[f]);
             }
         }
     }

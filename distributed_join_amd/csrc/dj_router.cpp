@@ -115,9 +115,12 @@ struct Set {
     uint32_t* matrix_h = nullptr;     // pinned copy
     dj_join_rec* recv_recs = nullptr;
     uint8_t* recv_pay = nullptr;
-    hipEvent_t counts_ev = nullptr, ready = nullptr, freed = nullptr;
+    hipEvent_t parted = nullptr, counts_ev = nullptr, ready = nullptr, freed = nullptr;
     bool free_pending = false, has_pay = false, active = false, planned = false;
-    uint32_t n = 0, rounds = 0, round = 0;
+    uint32_t n = 0, rounds = 0;
+    uint32_t round = 0;               // pieces handed to the caller
+    uint32_t issued = 0;              // pieces whose exchange has been queued (round or round + 1)
+    uint32_t n_in = 0;                // rows of the piece queued last
     uint32_t bucket_off[MAX_RANKS];   // where each destination's bucket starts in recs_sorted
 };
 }  // namespace
@@ -129,7 +132,10 @@ struct dj_router {
     uint32_t max_send = 0, max_recv = 0;
     uint64_t pitch = 0;
     ncclComm_t comm = nullptr;
-    hipStream_t stream = nullptr, engine_stream = nullptr;
+    // Three stages on three streams: the partition kernels (stream), everything that goes through RCCL
+    // (comm_stream: its kernels hold a few compute units for as long as the links need, and would only add to
+    // the partition's time on one stream with it), and the engine's own stream that applies what arrived.
+    hipStream_t stream = nullptr, comm_stream = nullptr, engine_stream = nullptr;
     Set sets[MAX_DEPTH];
     std::string err;
     std::mutex mu;
@@ -173,17 +179,20 @@ extern "C" void dj_router_destroy(dj_router* r) {
     if (!r) return;
     (void)hipSetDevice(r->cfg.device);
     if (r->stream) (void)hipStreamSynchronize(r->stream);
+    if (r->comm_stream) (void)hipStreamSynchronize(r->comm_stream);
     for (int k = 0; k < r->depth; ++k) {
         Set& s = r->sets[k];
         (void)hipFree(s.recs_sorted); (void)hipFree(s.pay_sorted); (void)hipFree(s.origin); (void)hipFree(s.counts);
         (void)hipFree(s.matrix_d); (void)hipFree(s.recv_recs); (void)hipFree(s.recv_pay);
         if (s.matrix_h) (void)hipHostFree(s.matrix_h);
+        if (s.parted) (void)hipEventDestroy(s.parted);
         if (s.counts_ev) (void)hipEventDestroy(s.counts_ev);
         if (s.ready) (void)hipEventDestroy(s.ready);
         if (s.freed) (void)hipEventDestroy(s.freed);
     }
     if (r->comm) (void)g_rccl.CommDestroy(r->comm);
     if (r->stream) (void)hipStreamDestroy(r->stream);
+    if (r->comm_stream) (void)hipStreamDestroy(r->comm_stream);
     delete r;
 }
 
@@ -205,6 +214,7 @@ extern "C" int dj_router_create(dj_engine* e, uint32_t n_ranks, uint32_t rank, c
     auto body = [&]() -> int {
         R_HIP(nullptr, hipSetDevice(r->cfg.device));
         R_HIP(nullptr, hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking));
+        R_HIP(nullptr, hipStreamCreateWithFlags(&r->comm_stream, hipStreamNonBlocking));
         r->engine_stream = (hipStream_t)dj_stream(e);
         for (int k = 0; k < r->depth; ++k) {
             Set& s = r->sets[k];
@@ -216,6 +226,7 @@ extern "C" int dj_router_create(dj_engine* e, uint32_t n_ranks, uint32_t rank, c
             R_HIP(nullptr, hipHostMalloc((void**)&s.matrix_h, (size_t)MAX_RANKS * MAX_RANKS * 4, hipHostMallocDefault));
             R_HIP(nullptr, hipMalloc((void**)&s.recv_recs, (size_t)max_recv * 32));
             R_HIP(nullptr, hipMalloc((void**)&s.recv_pay, (size_t)max_recv * pitch));
+            R_HIP(nullptr, hipEventCreateWithFlags(&s.parted, hipEventDisableTiming));
             R_HIP(nullptr, hipEventCreateWithFlags(&s.counts_ev, hipEventDisableTiming));
             R_HIP(nullptr, hipEventCreateWithFlags(&s.ready, hipEventDisableTiming));
             R_HIP(nullptr, hipEventCreateWithFlags(&s.freed, hipEventDisableTiming));
@@ -249,27 +260,25 @@ extern "C" int dj_route_start(dj_router* r, uint32_t n, const dj_join_rec* d_rec
     s.has_pay = d_payloads != nullptr;
     s.n = n;
     s.planned = false;
-    s.round = s.rounds = 0;
+    s.round = s.rounds = s.issued = s.n_in = 0;
     int rc = dj_partition_joins(r->e, n, (uint32_t)r->world, d_recs, d_payloads, r->pitch, s.recs_sorted,
                                 s.has_pay ? s.pay_sorted : nullptr, s.origin, s.counts, r->stream);
     if (rc != DJ_OK) return rfail(r, rc, "route: partition failed: %s", dj_last_error(r->e));
+    R_HIP(r, hipEventRecord(s.parted, r->stream));
+    R_HIP(r, hipStreamWaitEvent(r->comm_stream, s.parted, 0));
     // everybody's bucket sizes to everybody (world * world words), then to this host without waiting
-    R_NCCL(r, g_rccl.AllGather(s.counts, s.matrix_d, (size_t)r->world, ncclUint32, r->comm, r->stream));
-    R_HIP(r, hipMemcpyAsync(s.matrix_h, s.matrix_d, (size_t)r->world * r->world * 4, hipMemcpyDeviceToHost, r->stream));
-    R_HIP(r, hipEventRecord(s.counts_ev, r->stream));
+    R_NCCL(r, g_rccl.AllGather(s.counts, s.matrix_d, (size_t)r->world, ncclUint32, r->comm, r->comm_stream));
+    R_HIP(r, hipMemcpyAsync(s.matrix_h, s.matrix_d, (size_t)r->world * r->world * 4, hipMemcpyDeviceToHost, r->comm_stream));
+    R_HIP(r, hipEventRecord(s.counts_ev, r->comm_stream));
     s.active = true;
     *handle = r->turn;
     r->turn = (r->turn + 1) % r->depth;
     return DJ_OK;
 }
 
-extern "C" int dj_route_next(dj_router* r, int handle, const dj_join_rec** d_recs_out, const uint8_t** d_payloads_out,
-                             uint32_t* n_out, int* more) {
-    if (!r || handle < 0 || handle >= r->depth || !d_recs_out || !n_out || !more) return DJ_E_INVALID;
-    std::lock_guard<std::mutex> g(r->mu);
-    Set& s = r->sets[handle];
-    if (!s.active) return rfail(r, DJ_E_INVALID, "route: handle %d is not in flight", handle);
-    R_HIP(r, hipSetDevice(r->cfg.device));
+// Queues the exchange of piece s.issued on the communication stream (planning first, which waits for the bucket
+// sizes on the host) and records s.ready behind it.
+static int issue_piece(dj_router* r, Set& s) {
     const uint32_t w = (uint32_t)r->world;
     if (!s.planned) {
         R_HIP(r, hipEventSynchronize(s.counts_ev));      // already there when the start was issued a batch ahead
@@ -278,14 +287,14 @@ extern "C" int dj_route_next(dj_router* r, int handle, const dj_join_rec** d_rec
         s.rounds = dj_route_plan(w, (uint32_t)r->rank, s.matrix_h, r->max_recv, 0, nullptr, nullptr, nullptr);
         s.planned = true;
     } else {
-        if (s.round >= s.rounds) return rfail(r, DJ_E_INVALID, "route: handle %d has no piece left", handle);
+        if (s.issued >= s.rounds) return rfail(r, DJ_E_INVALID, "route: no piece left");
         // the receive buffers are reused: wait for what the engine's stream holds so far (the caller has
         // queued the kernels that read the previous piece)
         R_HIP(r, hipEventRecord(s.freed, r->engine_stream));
-        R_HIP(r, hipStreamWaitEvent(r->stream, s.freed, 0));
+        R_HIP(r, hipStreamWaitEvent(r->comm_stream, s.freed, 0));
     }
     uint32_t send_off[MAX_RANKS], send_cnt[MAX_RANKS], recv_cnt[MAX_RANKS];
-    dj_route_plan(w, (uint32_t)r->rank, s.matrix_h, r->max_recv, s.round, send_off, send_cnt, recv_cnt);
+    dj_route_plan(w, (uint32_t)r->rank, s.matrix_h, r->max_recv, s.issued, send_off, send_cnt, recv_cnt);
     uint32_t n_in = 0, at[MAX_RANKS];
     for (uint32_t p = 0; p < w; ++p) { at[p] = n_in; n_in += recv_cnt[p]; }
     for (int pass = 0; pass < (s.has_pay ? 2 : 1); ++pass) {
@@ -297,20 +306,47 @@ extern "C" int dj_route_next(dj_router* r, int handle, const dj_join_rec** d_rec
             const uint8_t* from = src + (size_t)(s.bucket_off[p] + send_off[p]) * row;
             uint8_t* to = dst + (size_t)at[p] * row;
             if ((int)p == r->rank) {
-                if (send_cnt[p]) R_HIP(r, hipMemcpyAsync(to, from, (size_t)send_cnt[p] * row, hipMemcpyDeviceToDevice, r->stream));
+                if (send_cnt[p]) R_HIP(r, hipMemcpyAsync(to, from, (size_t)send_cnt[p] * row, hipMemcpyDeviceToDevice, r->comm_stream));
                 continue;
             }
-            if (send_cnt[p]) R_NCCL(r, g_rccl.Send(from, (size_t)send_cnt[p] * row, ncclUint8, (int)p, r->comm, r->stream));
-            if (recv_cnt[p]) R_NCCL(r, g_rccl.Recv(to, (size_t)recv_cnt[p] * row, ncclUint8, (int)p, r->comm, r->stream));
+            if (send_cnt[p]) R_NCCL(r, g_rccl.Send(from, (size_t)send_cnt[p] * row, ncclUint8, (int)p, r->comm, r->comm_stream));
+            if (recv_cnt[p]) R_NCCL(r, g_rccl.Recv(to, (size_t)recv_cnt[p] * row, ncclUint8, (int)p, r->comm, r->comm_stream));
         }
         R_NCCL(r, g_rccl.GroupEnd());
     }
-    R_HIP(r, hipEventRecord(s.ready, r->stream));
+    R_HIP(r, hipEventRecord(s.ready, r->comm_stream));
+    s.n_in = n_in;
+    ++s.issued;
+    return DJ_OK;
+}
+
+extern "C" int dj_route_advance(dj_router* r, int handle) {
+    if (!r || handle < 0 || handle >= r->depth) return DJ_E_INVALID;
+    std::lock_guard<std::mutex> g(r->mu);
+    Set& s = r->sets[handle];
+    if (!s.active) return rfail(r, DJ_E_INVALID, "route: handle %d is not in flight", handle);
+    if (s.issued > 0) return DJ_OK;        // only the first piece can cross ahead: later ones reuse its buffers
+    R_HIP(r, hipSetDevice(r->cfg.device));
+    return issue_piece(r, s);
+}
+
+extern "C" int dj_route_next(dj_router* r, int handle, const dj_join_rec** d_recs_out, const uint8_t** d_payloads_out,
+                             uint32_t* n_out, int* more) {
+    if (!r || handle < 0 || handle >= r->depth || !d_recs_out || !n_out || !more) return DJ_E_INVALID;
+    std::lock_guard<std::mutex> g(r->mu);
+    Set& s = r->sets[handle];
+    if (!s.active) return rfail(r, DJ_E_INVALID, "route: handle %d is not in flight", handle);
+    R_HIP(r, hipSetDevice(r->cfg.device));
+    if (s.planned && s.round >= s.rounds) return rfail(r, DJ_E_INVALID, "route: handle %d has no piece left", handle);
+    if (s.issued == s.round) {             // not sent ahead by dj_route_advance
+        const int rc = issue_piece(r, s);
+        if (rc != DJ_OK) return rc;
+    }
     R_HIP(r, hipStreamWaitEvent(r->engine_stream, s.ready, 0));      // the engine's stream waits, the host does not
     ++s.round;
     *d_recs_out = s.recv_recs;
     if (d_payloads_out) *d_payloads_out = s.has_pay ? s.recv_pay : nullptr;
-    *n_out = n_in;
+    *n_out = s.n_in;
     *more = s.round < s.rounds ? 1 : 0;
     return DJ_OK;
 }

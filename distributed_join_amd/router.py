@@ -14,9 +14,11 @@ Skew: every rank holds the whole matrix of bucket sizes, so every rank computes 
 rows exceed its buffer (a hot key owns half of everybody's batch) takes them in several rounds, each a
 collective that all ranks enter.  No rank raises while its peers sit in a collective.
 
-The router works on its OWN stream with several buffer sets, so the routing of batches k+1 and
-k+2 runs while the engine's stream applies batch k, and start() never waits for the device: the
-host needs the bucket sizes only when the rows are exchanged (advance() / finish()), one batch later.
+The router works on two streams of its OWN with several buffer sets — one for the partition kernels, one for
+the collectives — so while the engine's stream applies batch k, batch k+1 is exchanged and batch k+2 is
+partitioned (the exchange's kernels occupy a few compute units for a long time: behind the partition on one
+stream they would only add to its time).  start() never waits for the device: the host needs the bucket
+sizes only when the rows are exchanged (advance() / finish()), one batch later.
     h = router.start(recs, payloads, n)      # partition + bucket sizes, asynchronous
     ...                                       # the engine applies the previous batch
     router.advance(h)                         # optional: exchange the first piece now (sizes are in by now)
@@ -109,6 +111,7 @@ class _Slot:
         self.matrix_h = torch.empty(world * world, dtype=torch.int32).pin_memory()
         self.recv_recs = torch.empty((max_recv, 4), dtype=torch.int64, device=dev)
         self.recv_pay = torch.empty((max_recv, pitch), dtype=torch.uint8, device=dev)
+        self.parted = torch.cuda.Event()     # the partition is done (recorded on the partition stream)
         self.sizes_in = torch.cuda.Event()   # the bucket sizes are in host memory
         self.ready = torch.cuda.Event()      # data has arrived (recorded on the router's stream)
         self.free = torch.cuda.Event()       # the engine has consumed it (recorded on the engine's stream)
@@ -131,7 +134,8 @@ class Router:
         self.pitch = int(pitch)
         self.max_recv = int(max_recv)
         dev = engine.device
-        self.stream = torch.cuda.Stream(device=dev)
+        self.stream = torch.cuda.Stream(device=dev)          # partition kernels
+        self.comm_stream = torch.cuda.Stream(device=dev)     # bucket sizes and rows between the ranks
         self.engine_stream = engine.torch_stream()
         self.slots = [_Slot(torch, dev, self.world, max_send, max_recv, self.pitch) for _ in range(max(2, int(depth)))]
         self.turn = 0
@@ -159,10 +163,13 @@ class Router:
                                        stream_ptr=self.stream.cuda_stream)
             if self.host_staged:
                 return s
+            s.parted.record(self.stream)
+        with torch.cuda.stream(self.comm_stream):
+            self.comm_stream.wait_event(s.parted)
             w = self.world
             self.dist.all_gather_into_tensor(s.matrix_d, s.counts[:w], group=self.group)
             s.matrix_h.copy_(s.matrix_d, non_blocking=True)
-            s.sizes_in.record(self.stream)
+            s.sizes_in.record(self.comm_stream)
         return s
 
     def _plan(self, s):
@@ -183,11 +190,12 @@ class Router:
     def _exchange(self, s):
         torch = self.torch
         self._plan(s)
-        with torch.cuda.stream(self.stream):
+        lane = self.stream if self.host_staged else self.comm_stream
+        with torch.cuda.stream(lane):
             if s.round > 0:
                 # the receive buffers are reused: the engine's kernels that read the previous piece are queued
                 s.free.record(self.engine_stream)
-                self.stream.wait_event(s.free)
+                lane.wait_event(s.free)
             if self.host_staged:
                 rr = torch.empty((self.max_recv, 4), dtype=torch.int64)
                 rp = torch.empty((self.max_recv, self.pitch), dtype=torch.uint8) if s.has_pay else None
@@ -200,7 +208,7 @@ class Router:
             else:
                 s.n_in, s.rounds = exchange_round(self.dist, self.group, self.rank, s.matrix, self.max_recv, s.round,
                                                   s.recs_sorted, s.pay_sorted if s.has_pay else None, s.recv_recs, s.recv_pay)
-            s.ready.record(self.stream)
+            s.ready.record(lane)
         s.round += 1
 
     def advance(self, s):

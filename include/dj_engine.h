@@ -357,13 +357,20 @@ int dj_partition_joins(dj_engine* e, uint32_t n, uint32_t n_ranks,
 uint32_t dj_route_plan(uint32_t n_ranks, uint32_t rank, const uint32_t* matrix, uint64_t max_recv, uint32_t round,
                        uint32_t* send_off, uint32_t* send_cnt, uint32_t* recv_cnt);
 
-/* A router owns a stream of its own, `depth` sets of send/receive buffers and an RCCL communicator over the
+/* A router owns two streams of its own (one for the partition kernels, one for everything that goes through
+ * RCCL), `depth` sets of send/receive buffers and an RCCL communicator over the
  * n_ranks engines of one node (librccl is bound at run time; only these calls need it).  Rank 0 makes an id
  * with dj_route_unique_id and hands the 128 bytes to every rank by whatever channel the host has; every rank
  * then calls dj_router_create (a collective).  One batch:
- *   dj_route_start   partition + all-gather of the bucket sizes, queued on the router's stream; the host
+ *   dj_route_start   partition + all-gather of the bucket sizes, queued on the router's streams; the host
  *                    does not wait.  Start the next batches while the engine applies this one.
- *   dj_route_next    exchanges the next piece (grouped ncclSend/ncclRecv of records, then messages) and makes
+ *   dj_route_advance optional: queues the exchange of the batch's FIRST piece now, without making the engine's
+ *                    stream wait for it, so that batch k+1's rows cross the links while the engine applies batch
+ *                    k and batch k+2 is partitioned (call it for k+1 once batch k's engine calls are queued, and
+ *                    before the dj_route_start of k+2, whose all-gather would otherwise stand in front of it on
+ *                    the communication stream).  The host waits for the bucket sizes as in dj_route_next.
+ *   dj_route_next    exchanges the next piece (grouped ncclSend/ncclRecv of records, then messages) unless
+ *                    dj_route_advance already has, and makes
  *                    the ENGINE's stream wait for its arrival; the host waits only for the bucket sizes, which
  *                    are in when the start was issued a batch ahead.  Returns device pointers to this rank's
  *                    records / messages, their number and whether more pieces follow (skew beyond max_recv).
@@ -378,6 +385,7 @@ int  dj_router_create(dj_engine* e, uint32_t n_ranks, uint32_t rank, const uint8
 void dj_router_destroy(dj_router* r);
 const char* dj_router_last_error(const dj_router* r);     /* r may be NULL: last create / id error of this thread */
 int  dj_route_start(dj_router* r, uint32_t n, const dj_join_rec* d_recs, const uint8_t* d_payloads, int* handle);
+int  dj_route_advance(dj_router* r, int handle);
 int  dj_route_next(dj_router* r, int handle, const dj_join_rec** d_recs_out, const uint8_t** d_payloads_out,
                    uint32_t* n_out, int* more);
 int  dj_route_release(dj_router* r, int handle);

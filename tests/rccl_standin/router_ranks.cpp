@@ -5,7 +5,8 @@
 // Every rank routes B batches of n records with their messages; a share of all records names one hot barrier, so its
 // owner's incoming rows exceed max_recv and every batch takes several rounds.  Checked per rank and batch: the pieces,
 // put one behind the other, are exactly the records this rank owns (dj_owner_of) from rank 0's batch in array order,
-// then from rank 1's, ..., each with its message.  Batches are started ahead (two in flight) as a pipelined host would.
+// then from rank 1's, ..., each with its message.  Batches are started ahead (two in flight) and every other batch's
+// first piece is sent ahead of its use (dj_route_advance), as a pipelined host would.
 //
 //   usage: router_ranks <ranks> <records per rank and batch> <max_recv> <hot percent> [batches]
 #include <hip/hip_runtime.h>
@@ -118,6 +119,10 @@ int main(int argc, char** argv) {
             };
             start(0);
             for (int b = 0; b < B; ++b) {
+                if (b % 2 == 0 && dj_route_advance(rt, handle[b]) != DJ_OK) {     // before the next start, as the header says
+                    fprintf(stderr, "rank %d: advance: %s\n", r, dj_router_last_error(rt));
+                    exit(2);
+                }
                 if (b + 1 < B) start(b + 1);                 // the next batch's partition and sizes are under way
                 std::vector<dj_join_rec> got;
                 std::vector<uint8_t> got_pay;

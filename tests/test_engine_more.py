@@ -58,14 +58,15 @@ def test_sweep_caps_leave_the_rest_queued(oracle_lib):
 
 @pytest.mark.parametrize("n_ranks,n,pitch", [(1, 100_003, 48), (2, 100_003, 48), (3, 100_003, 48), (8, 100_003, 48),
                                             (8, 1, 64), (5, 63, 16), (8, 1025, 64), (64, 70_001, 32), (7, 5_000, 1024),
-                                            (4, 3_001, 2064), (8, 1 << 17, 64), (6, 4_097, 0), (64, (1 << 18) - 5, 16)])
+                                            (4, 3_001, 2064), (8, 1 << 17, 64), (6, 4_097, 0), (64, (1 << 18) - 5, 16), (8, (1 << 20) + 77, 16),
+                                            (3, (1 << 21) - 1029, 0)])
 def test_partition_kernel_is_a_stable_partition_by_owner(n_ranks, n, pitch):
-    """Rows of any width (pitch 0: records only), batches that end inside a tile, a wave or on a tile's edge, and as many
-    owners as a wave has lanes."""
+    """Rows of any width (pitch 0: records only), batches that end inside a tile, a wave or on a tile's edge, as many
+    owners as a wave has lanes, and batches large enough for a block to take several tiles."""
     import torch
     from distributed_join_amd.router import owner_of_np
     rng = np.random.default_rng(n_ranks + n)
-    e = _engine(capacity_barriers=64, arena_bytes=1 << 20, max_count=8, payload_stride=64, max_batch=1 << 18)
+    e = _engine(capacity_barriers=64, arena_bytes=1 << 20, max_count=8, payload_stride=64, max_batch=1 << 21)
     try:
         recs = np.zeros(n, dtype=capi.JOIN_REC)
         recs["fp_lo"] = rng.integers(2, 1 << 62, n, dtype=np.uint64)
@@ -946,7 +947,7 @@ def test_replay_storm_at_full_batch_size(hot_mode):
 def test_native_router_single_rank_roundtrip():
     """The C router (dj_router_*: RCCL bound at run time, bucket sizes all-gathered, planned pieces) with one rank
     and receive buffers smaller than the batch: every record and message comes back, in array order, over
-    several pieces."""
+    several pieces, with the first piece sent ahead (dj_route_advance) or not."""
     import ctypes
     import torch
     L = capi.load()
@@ -961,9 +962,12 @@ def test_native_router_single_rank_roundtrip():
     r = ctypes.c_void_p()
     assert L.dj_router_create(e.h, 1, 0, uid, n, cap, pitch, 2, ctypes.byref(r)) == 0, L.dj_router_last_error(None)
     try:
-        for with_pay in (True, False):
+        for with_pay, ahead in ((True, False), (False, True), (True, True)):
             h = ctypes.c_int(-1)
             assert L.dj_route_start(r, n, recs.data_ptr(), pay.data_ptr() if with_pay else None, ctypes.byref(h)) == 0
+            if ahead:
+                assert L.dj_route_advance(r, h.value) == 0, L.dj_router_last_error(r)
+                assert L.dj_route_advance(r, h.value) == 0        # a second call changes nothing
             got_r, got_p, pieces, more = [], [], 0, ctypes.c_int(1)
             while more.value:
                 pr, pp, pn = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint32()
