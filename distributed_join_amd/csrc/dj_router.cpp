@@ -297,23 +297,31 @@ static int issue_piece(dj_router* r, Set& s) {
     dj_route_plan(w, (uint32_t)r->rank, s.matrix_h, r->max_recv, s.issued, send_off, send_cnt, recv_cnt);
     uint32_t n_in = 0, at[MAX_RANKS];
     for (uint32_t p = 0; p < w; ++p) { at[p] = n_in; n_in += recv_cnt[p]; }
-    for (int pass = 0; pass < (s.has_pay ? 2 : 1); ++pass) {
-        const size_t row = pass == 0 ? 32 : (size_t)r->pitch;
-        const uint8_t* src = pass == 0 ? reinterpret_cast<const uint8_t*>(s.recs_sorted) : s.pay_sorted;
-        uint8_t* dst = pass == 0 ? reinterpret_cast<uint8_t*>(s.recv_recs) : s.recv_pay;
-        R_NCCL(r, g_rccl.GroupStart());
-        for (uint32_t p = 0; p < w; ++p) {
-            const uint8_t* from = src + (size_t)(s.bucket_off[p] + send_off[p]) * row;
-            uint8_t* to = dst + (size_t)at[p] * row;
-            if ((int)p == r->rank) {
-                if (send_cnt[p]) R_HIP(r, hipMemcpyAsync(to, from, (size_t)send_cnt[p] * row, hipMemcpyDeviceToDevice, r->comm_stream));
-                continue;
+    // records and messages of all peers in ONE group: one RCCL launch per piece (both sides issue records first,
+    // then messages, so the two transfers between a pair of ranks match up in that order)
+    R_NCCL(r, g_rccl.GroupStart());
+    auto queue_transfers = [&]() -> int {
+        for (int pass = 0; pass < (s.has_pay ? 2 : 1); ++pass) {
+            const size_t row = pass == 0 ? 32 : (size_t)r->pitch;
+            const uint8_t* src = pass == 0 ? reinterpret_cast<const uint8_t*>(s.recs_sorted) : s.pay_sorted;
+            uint8_t* dst = pass == 0 ? reinterpret_cast<uint8_t*>(s.recv_recs) : s.recv_pay;
+            for (uint32_t p = 0; p < w; ++p) {
+                const uint8_t* from = src + (size_t)(s.bucket_off[p] + send_off[p]) * row;
+                uint8_t* to = dst + (size_t)at[p] * row;
+                if ((int)p == r->rank) {
+                    if (send_cnt[p]) R_HIP(r, hipMemcpyAsync(to, from, (size_t)send_cnt[p] * row, hipMemcpyDeviceToDevice, r->comm_stream));
+                    continue;
+                }
+                if (send_cnt[p]) R_NCCL(r, g_rccl.Send(from, (size_t)send_cnt[p] * row, ncclUint8, (int)p, r->comm, r->comm_stream));
+                if (recv_cnt[p]) R_NCCL(r, g_rccl.Recv(to, (size_t)recv_cnt[p] * row, ncclUint8, (int)p, r->comm, r->comm_stream));
             }
-            if (send_cnt[p]) R_NCCL(r, g_rccl.Send(from, (size_t)send_cnt[p] * row, ncclUint8, (int)p, r->comm, r->comm_stream));
-            if (recv_cnt[p]) R_NCCL(r, g_rccl.Recv(to, (size_t)recv_cnt[p] * row, ncclUint8, (int)p, r->comm, r->comm_stream));
         }
-        R_NCCL(r, g_rccl.GroupEnd());
-    }
+        return DJ_OK;
+    };
+    const int queued = queue_transfers();
+    const ncclResult_t ended = g_rccl.GroupEnd();          // the group is closed whatever happened inside it
+    if (queued != DJ_OK) return queued;
+    R_NCCL(r, ended);
     R_HIP(r, hipEventRecord(s.ready, r->comm_stream));
     s.n_in = n_in;
     ++s.issued;
