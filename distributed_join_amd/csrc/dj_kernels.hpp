@@ -165,16 +165,28 @@ __device__ inline void wave_copy_rows(const Table& t, const uint8_t* payloads, u
     constexpr int EPS = 64 / G;                     // events per step
     const uint32_t lane = threadIdx.x & 63, sub = lane / G, j0 = lane % G;
     const uint32_t rlo = (uint32_t)row_off, rhi = (uint32_t)(row_off >> 32);
+    // A row is at most G chunks (one per lane of its group: G * 16 bytes cover the stride).  Four steps' loads are
+    // issued before the first store, so a wave waits for memory once per four rows instead of once per row.
+    constexpr int FLIGHT = 4;
 #pragma unroll 1
-    for (int step = 0; step < G; ++step) {
-        const int src = step * EPS + (int)sub;
-        const uint64_t row = ((uint64_t)__shfl(rhi, src) << 32) | __shfl(rlo, src);
-        const uint32_t ln = __shfl(len, src);
-        if (row == ~0ull) continue;
-        const uint4* from = reinterpret_cast<const uint4*>(payloads + (ev0 + (uint64_t)src) * pitch);
-        uint4* to = reinterpret_cast<uint4*>(t.arena + row);
-        const uint32_t chunks = (ln + 15) >> 4, full = (chunks + 3) & ~3u;
-        for (uint32_t c = j0; c < full; c += G) nt_store(&to[c], c < chunks ? nt_load(&from[c]) : make_uint4(0, 0, 0, 0));
+    for (int step0 = 0; step0 < G; step0 += FLIGHT) {
+        uint4 v[FLIGHT];
+        uint4* to[FLIGHT];
+        bool on[FLIGHT];
+#pragma unroll
+        for (int f = 0; f < FLIGHT; ++f) {
+            const int src = (step0 + f) * EPS + (int)sub;
+            const uint64_t row = ((uint64_t)__shfl(rhi, src) << 32) | __shfl(rlo, src);
+            const uint32_t ln = __shfl(len, src);
+            const uint32_t chunks = (ln + 15) >> 4, full = (chunks + 3) & ~3u;
+            on[f] = row != ~0ull && j0 < full;
+            to[f] = reinterpret_cast<uint4*>(t.arena + (on[f] ? row : 0)) + j0;
+            v[f] = make_uint4(0, 0, 0, 0);
+            if (on[f] && j0 < chunks) v[f] = nt_load(&reinterpret_cast<const uint4*>(payloads + (ev0 + (uint64_t)src) * pitch)[j0]);
+        }
+#pragma unroll
+        for (int f = 0; f < FLIGHT; ++f)
+            if (on[f]) nt_store(to[f], v[f]);
     }
 }
 
