@@ -1578,7 +1578,7 @@ __device__ inline void retry_requeue(const Table& t, uint64_t s, bool timeout, u
     note_queue_date(t, s, now);
 }
 
-constexpr int ACK_BLOCK = 1024;
+constexpr int ACK_BLOCK = 512;
 
 __global__ void __launch_bounds__(ACK_BLOCK) ack_kernel(Table t, uint32_t n_max, const uint32_t* d_n, const dj_cont* conts,
                                                         const uint8_t* ok, uint64_t now, int32_t* status) {
