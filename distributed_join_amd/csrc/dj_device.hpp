@@ -734,6 +734,21 @@ __device__ inline void fill_posmeta_default(const Table& t, uint32_t slab, uint3
     for (uint32_t j = 0; j < n16; ++j) pm[j] = v;
 }
 
+// The same for every lane of a wave that wants it (call with the whole wave).  Slabs of up to 16 positions are
+// filled by their own lane (a line or two); larger ones one after the other by all 64 lanes, 16 bytes each per
+// step, instead of one lane writing up to 8 KB in a loop while its neighbours wait.
+__device__ inline void wave_fill_posmeta_each(const Table& t, bool want, uint32_t slab, uint32_t k) {
+    const uint32_t n16 = want ? (slab_payload_off(k) - slab_posmeta_off(k)) >> 4 : 0;
+    if (want && n16 <= 8) fill_posmeta_default(t, slab, k);
+    const uint4 v = make_uint4(t.stride, 0, t.stride, 0);
+    for (uint64_t m = __ballot(want && n16 > 8); m; m &= m - 1) {
+        const int l = __ffsll((unsigned long long)m) - 1;
+        const uint32_t sb = __shfl(slab, l), kk = __shfl(k, l), cnt = __shfl(n16, l);
+        uint4* pm = reinterpret_cast<uint4*>(slab_posmeta(t, sb, kk));
+        for (uint32_t j = lane_id(); j < cnt; j += 64) pm[j] = v;
+    }
+}
+
 // node packing of the join link pass: next (25) | position (10) | max-wait (29)
 constexpr uint32_t NODE_MW_LIMIT = 1u << 29;
 __device__ inline uint64_t node_pack(uint32_t next, uint32_t pos, uint32_t mw) {

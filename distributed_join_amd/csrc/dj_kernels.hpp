@@ -111,14 +111,14 @@ __global__ void __launch_bounds__(FORK_APPLY_BLOCK) fork_apply_kernel(Table t, W
             slab = fresh;
         }
     }
+    // pre-filled words are what a barrier without META_PMD relies on; with long messages enabled the words of
+    // absent positions are read as well (none may look like a long message)
+    wave_fill_posmeta_each(t, ok && (!t.fork_pmd || long_on), slab, k_new);
     if (ok) {
         if (r.count > 64) {
             uint64_t* bm = slab_bitmap(t, slab);
             for (uint32_t j = 0; j < (class_positions(k_new) >> 6); ++j) bm[j] = 0;
         }
-        // pre-filled words are what a barrier without META_PMD relies on; with long messages enabled the words of
-        // absent positions are read as well (none may look like a long message)
-        if (!t.fork_pmd || long_on) fill_posmeta_default(t, slab, k_new);
         sl->count = r.count;                                  // SET <id>:metadata
         sl->meta = meta_pack(true, RETRY_NIL, RETRY_NIL) | (t.fork_pmd ? META_PMD : 0u);
         sl->slab = slab;
