@@ -596,9 +596,9 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
     // register replay takes chains up to 16 (slower for everyone else, far cheaper than a wave per barrier)
     const bool wide = e->cx_force >= 0 ? (e->cx_force & 2) != 0 : hint[8] >= WIDE_ON;
     if (wide)
-        LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_kernel<CHAIN_REG_WIDE><<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, w, (uint32_t)n, now_ms, d_status)));
+        LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_kernel<CHAIN_REG_WIDE><<<grid_for(n, RESOLVE_BLOCK), RESOLVE_BLOCK, 0, e->stream>>>(e->t, w, (uint32_t)n, now_ms, d_status)));
     else
-        LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_kernel<CHAIN_REG><<<grid_for(n, 256), 256, 0, e->stream>>>(e->t, w, (uint32_t)n, now_ms, d_status)));
+        LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_kernel<CHAIN_REG><<<grid_for(n, RESOLVE_BLOCK), RESOLVE_BLOCK, 0, e->stream>>>(e->t, w, (uint32_t)n, now_ms, d_status)));
     // Long chains (hot barriers): the previous batch's longest chain, read back without waiting, picks
     // between the serial kernel and the parallel cx_* kernels.  Both give the same results.
     // One wave per long chain; the grid follows the previous batch's number of them (an empty pass of 4096

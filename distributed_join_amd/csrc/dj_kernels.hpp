@@ -377,9 +377,10 @@ __device__ inline int32_t replay_one(const Table& t, uint64_t s, uint32_t slab, 
 // (more registers, fewer resident waves) while many barriers receive 9..16 events per batch, which would
 // otherwise each take a wave of the long-chain kernels.
 constexpr int CHAIN_REG = 8, CHAIN_REG_WIDE = 16;
+constexpr int RESOLVE_BLOCK = 512;
 
 template <int CR>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CR <= 8 ? 8 : 4)))
+__global__ void __launch_bounds__(RESOLVE_BLOCK) __attribute__((amdgpu_waves_per_eu(CR <= 8 ? 8 : 4)))
 join_resolve_kernel(Table t, Work w, uint32_t n, uint64_t now, int32_t* status) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     // block pops of the copy pass stop at the tails as they are now (nothing touches these rings here)
