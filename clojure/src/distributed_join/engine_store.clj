@@ -32,50 +32,50 @@
 
 ;; ---- native libraries -------------------------------------------------------------------------
 
-(def ^:private ^NativeLibrary dj (NativeLibrary/getInstance "dj_engine"))
+(def ^NativeLibrary dj (NativeLibrary/getInstance "dj_engine"))
 (def ^:private ^NativeLibrary hip (NativeLibrary/getInstance "amdhip64"))
 
-(defn- native-int
+(defn native-int
   "Calls an int-returning C function.  Arguments must already have their C width:
   (int x) for 32-bit parameters, (long x) for 64-bit ones, Pointer / byte[] for pointers."
   [^NativeLibrary lib ^String fname & args]
   (.invokeInt ^Function (.getFunction lib fname) (to-array args)))
 
-(defn- check [rc what]
+(defn check [rc what]
   (when (neg? rc)
     ;; redis.clj:17-21: internal failures surface as ex-info with :causes -> HTTP 500
     (throw (ex-info "Database failure(s)" {:causes [(str what " failed with " rc)]})))
   rc)
 
-(defn- use-device
+(defn use-device
   "HIP's current device is per thread; manifold future threads come and go."
   []
   (check (- (native-int hip "hipSetDevice" (int (or (:engine-device env) 0)))) "hipSetDevice"))
 
-(defn- device-alloc ^Pointer [^long bytes]
+(defn device-alloc ^Pointer [^long bytes]
   (use-device)
   (let [ref (PointerByReference.)]
     (check (- (native-int hip "hipMalloc" ref (long bytes))) "hipMalloc")
     (.getValue ref)))
 
-(defn- to-host ^Memory [^Pointer device ^long bytes]
+(defn to-host ^Memory [^Pointer device ^long bytes]
   (use-device)
   (let [m (Memory. (max bytes 1))]
     (check (- (native-int hip "hipMemcpy" m device (long bytes) (int 2))) "hipMemcpy")   ; device to host
     m))
 
-(defn- to-device [^Pointer device ^Memory host ^long bytes]
+(defn to-device [^Pointer device ^Memory host ^long bytes]
   (use-device)
   (check (- (native-int hip "hipMemcpy" device host (long bytes) (int 1))) "hipMemcpy"))  ; host to device
 
 ;; ---- engine and batcher -----------------------------------------------------------------------
 
-(def ^:private payload-stride (long (or (:engine-payload-stride env) 256)))
-(def ^:private max-count (long (:fork-count-max env)))                 ; config.edn:33
-(def ^:private max-message (long (:join-message-len-max env)))         ; config.edn:38, in characters (store.clj:24-26)
+(def payload-stride (long (or (:engine-payload-stride env) 256)))
+(def max-count (long (:fork-count-max env)))                 ; config.edn:33
+(def max-message (long (:join-message-len-max env)))         ; config.edn:38, in characters (store.clj:24-26)
 ;; the engine stores UTF-8 bytes: at most three per UTF-16 code unit of a String
 (def ^:private max-message-bytes (long (min (* 3 max-message) (bit-shift-left 1 20))))
-(def ^:private sweep-cap (long (or (:engine-sweep-cap env) 65536)))    ; continuations per poll
+(def sweep-cap (long (or (:engine-sweep-cap env) 65536)))    ; continuations per poll
 
 (defn- make-config ^Memory []
   ;; struct dj_config, 56 bytes (include/dj_engine.h)
@@ -92,12 +92,12 @@
     (.setInt 44 (int max-message-bytes))
     (.setLong 48 (long (:check-publish-delay-ms env)))))               ; config.edn:16
 
-(defonce ^:private engine
+(defonce engine
   (delay (let [ref (PointerByReference.)]
            (check (native-int dj "dj_create" (make-config) ref) "dj_create")
            (.getValue ref))))
 
-(defonce ^:private batcher
+(defonce batcher
   (delay (let [cfg (doto (Memory. 16)                                  ; struct dj_batcher_config
                      (.setInt 0 (int 16))
                      (.setInt 4 (int (or (:engine-batcher-max-batch env) 65536)))
@@ -109,9 +109,9 @@
 
 ;; device buffers of the publisher (one sweep / ack / recover at a time: the two scheduler threads of
 ;; ring.clj:113-114 take this lock around their poll)
-(defonce ^:private publisher-lock (Object.))
+(defonce publisher-lock (Object.))
 (defonce ^:private last-sweep-rows (atom 0))       ; rows the last sweep wrote, unused (void) ones included
-(defonce ^:private buffers
+(defonce buffers
   (delay (let [positions (* sweep-cap max-count)]
            {:conts    (device-alloc (* 64 sweep-cap))
             :lens     (device-alloc (* 4 positions))
@@ -123,17 +123,17 @@
 
 ;; ---- what stays on the JVM: id strings and the Fork maps (URLs), keyed by fingerprint -----------
 
-(defonce ^:private ^ConcurrentHashMap forks (ConcurrentHashMap.))      ; [fp-lo fp-hi] -> Fork map with :timeout-secs
+(defonce ^ConcurrentHashMap forks (ConcurrentHashMap.))      ; [fp-lo fp-hi] -> Fork map with :timeout-secs
 
-(defn- utf8 ^bytes [^String s] (.getBytes s StandardCharsets/UTF_8))
+(defn utf8 ^bytes [^String s] (.getBytes s StandardCharsets/UTF_8))
 
-(defn- fingerprint [^String barrier-id]
+(defn fingerprint [^String barrier-id]
   (let [b (utf8 barrier-id) out (Memory. 16)]
     (.invokeVoid ^Function (.getFunction dj "dj_fingerprint")
                  (to-array [b (long (alength b)) out (.share out 8)]))
     [(.getLong out 0) (.getLong out 8)]))
 
-(defn- barrier-id-of [record]
+(defn barrier-id-of [record]
   (str (:join-id record) "~" (:transaction-id record)))                ; make-key, redis.clj:42-45
 
 ;; ---- requests ------------------------------------------------------------------------------------
@@ -156,33 +156,47 @@
         (do (if previous (.put forks fp previous) (.remove forks fp))    ; a refused fork leaves the barrier as it was
             (throw (ex-info "Database failure(s)" {:causes [(str "engine limit reached: " (.getInt status 0))]})))))))
 
+(defn join-status
+  "record: the Join map (store.clj:19-28).  Deferred of the engine's DJ_JOIN_* status of the event."
+  [record]
+  (deferred/future
+    (let [[lo hi] (fingerprint (:barrier-id record))
+          message (utf8 (:message record))
+          rec (doto (Memory. 32)                                       ; struct dj_join_rec
+                (.setLong 0 lo) (.setLong 8 hi)
+                (.setInt 16 (int (:position record)))
+                (.setInt 20 (int (alength message)))
+                (.setInt 24 (int (or (:max-wait record) 0)))
+                (.setInt 28 (int 0)))
+          status (Memory. 4)]
+      (check (native-int dj "dj_batcher_join_wait" @batcher rec message status) "dj_batcher_join_wait")
+      (.getInt status 0))))
+
+(defn join-failure
+  "The error deferred of a refused join (the texts of redis.clj:152-153), nil for a status that stored the message."
+  [status]
+  (case (int status)
+    (1 2 5) nil
+    3 (err ::handling/not-found "barrier-id does not exist")
+    4 (err ::handling/bad-data "position is greater than total")
+    6 (err ::handling/bad-data (str "Message length cannot exceed " max-message))
+    (deferred/error-deferred (ex-info "Database failure(s)" {:causes [(str "join status " status)]}))))
+
 (defn join
   "record: the Join map (store.clj:19-28).  Deferred of {:complete? bool}; 404 / 400 as error
   deferreds with the texts of redis.clj:152-153."
   [record]
   (deferred/chain
-    (deferred/future
-      (let [[lo hi] (fingerprint (:barrier-id record))
-            message (utf8 (:message record))
-            rec (doto (Memory. 32)                                     ; struct dj_join_rec
-                  (.setLong 0 lo) (.setLong 8 hi)
-                  (.setInt 16 (int (:position record)))
-                  (.setInt 20 (int (alength message)))
-                  (.setInt 24 (int (or (:max-wait record) 0)))
-                  (.setInt 28 (int 0)))
-            status (Memory. 4)]
-        (check (native-int dj "dj_batcher_join_wait" @batcher rec message status) "dj_batcher_join_wait")
-        (.getInt status 0)))
+    (join-status record)
     (fn [status]
-      (case (int status)
-        1 {:complete? false}                                           ; DJ_JOIN_WAITING
-        2 {:complete? true}                                            ; DJ_JOIN_COMPLETE
-        3 (err ::handling/not-found "barrier-id does not exist")
-        4 (err ::handling/bad-data "position is greater than total")
-        6 (err ::handling/bad-data (str "Message length cannot exceed " max-message))
-        (deferred/error-deferred (ex-info "Database failure(s)" {:causes [(str "join status " status)]}))))))
+      (or (join-failure status)
+          (case (int status)
+            1 {:complete? false}                                       ; DJ_JOIN_WAITING
+            2 {:complete? true}                                        ; DJ_JOIN_COMPLETE
+            ;; DJ_JOIN_NEAREST_NOT_QUEUED: the Lua compare of redis.clj:268-269 raised after the message was stored
+            (deferred/error-deferred (ex-info "Database failure(s)" {:causes [(str "join status " status)]})))))))
 
-(defn- read-messages
+(defn read-messages
   "Positions 0..count-1 of one barrier from host copies of the lens / max-waits / payload arrays:
   a vector of Join-shaped maps, nil where the position is missing (as-array, redis.clj:76-80)."
   [barrier-id ^Memory lens ^Memory waits ^Memory payloads ^long base ^long cnt]
@@ -196,22 +210,36 @@
                   (pos? wait) (assoc :max-wait wait))))))
         (range cnt)))
 
+(defn- metadata-of
+  "The metadata map of redis/join-metadata: the Fork map this JVM holds for the id, with the fields the engine
+  owns read from the dj_cont at h-meta (:count, :timeout-secs, the two retry counters when they are set)."
+  [fp ^Memory h-meta]
+  (let [retry-publish (.getInt h-meta 40)
+        retry-timeout (.getInt h-meta 44)]
+    (cond-> (assoc (or (.get forks fp) {})
+                   :count (.getInt h-meta 32)
+                   :timeout-secs (.getLong h-meta 16))
+      (not= -1 retry-publish) (assoc :publish-retry-cnt retry-publish)           ; DJ_NIL
+      (not= -1 retry-timeout) (assoc :timeout-publish-retry-cnt retry-timeout))))
+
 (defn snapshot
-  "Deferred of {:metadata Fork-map :joins [join-or-nil ...]} or nil when the id has no metadata
-  (join-metadata + all-joins-status, redis.clj:245-253; no timestamp update)."
-  [barrier-id]
-  (deferred/future
-    (locking publisher-lock
-      (let [[lo hi :as fp] (fingerprint barrier-id)
-            meta (Memory. 64)
-            lens (Memory. (* 4 max-count))
-            waits (Memory. (* 4 max-count))
-            payloads (Memory. (* payload-stride max-count))]
-        (check (native-int dj "dj_snapshot_one" @engine (long lo) (long hi) (int 0) meta lens waits payloads)
-               "dj_snapshot_one")
-        (when (zero? (bit-and 2 (.getInt meta 36)))                    ; DJ_CONT_NO_METADATA
-          {:metadata (or (.get forks fp) {:count (.getInt meta 32)})
-           :joins    (read-messages barrier-id lens waits payloads 0 (.getInt meta 32))})))))
+  "Deferred of {:metadata map :joins [join-or-nil ...]} or nil when the id has no metadata
+  (join-metadata + all-joins-status, redis.clj:245-253).  update-ts? true is redis/all-joins
+  (redis.clj:242-243): join-ts-read := join-ts."
+  ([barrier-id] (snapshot barrier-id false))
+  ([barrier-id update-ts?]
+   (deferred/future
+     (locking publisher-lock
+       (let [[lo hi :as fp] (fingerprint barrier-id)
+             meta (Memory. 64)
+             lens (Memory. (* 4 max-count))
+             waits (Memory. (* 4 max-count))
+             payloads (Memory. (* payload-stride max-count))]
+         (check (native-int dj "dj_snapshot_one" @engine (long lo) (long hi) (int (if update-ts? 1 0)) meta lens waits payloads)
+                "dj_snapshot_one")
+         (when (zero? (bit-and 2 (.getInt meta 36)))                    ; DJ_CONT_NO_METADATA
+           {:metadata (metadata-of fp meta)
+            :joins    (read-messages barrier-id lens waits payloads 0 (.getInt meta 32))}))))))
 
 ;; ---- publisher -------------------------------------------------------------------------------------
 

@@ -23,6 +23,7 @@ DJ_JOIN_NO_SPACE = 8
 DJ_FORK_CREATED, DJ_FORK_TABLE_FULL, DJ_FORK_NO_SPACE, DJ_FORK_BAD_COUNT = 1, 2, 3, 4
 DJ_ACK_DONE, DJ_ACK_REQUEUED_DIRTY, DJ_ACK_RETRY = 1, 2, 3
 DJ_ACK_DROPPED_EXHAUSTED, DJ_ACK_DONE_NO_METADATA = 4, 5
+DJ_ACK_DIRTY, DJ_ACK_METADATA_SET = 6, 7
 DJ_CONT_TIMEOUT, DJ_CONT_NO_METADATA = 1, 2
 DJ_CONT_VOID = CONT_VOID = 0x80000000
 DJ_STATIC_JOIN_MAX = 65536
@@ -60,7 +61,8 @@ SYMBOLS = ["dj_create", "dj_destroy", "dj_last_error", "dj_sync", "dj_stream", "
            "dj_profile_read", "dj_compact", "dj_set_hot_path", "dj_checkpoint_save", "dj_checkpoint_load",
            "dj_get_config", "dj_fetch_long", "dj_join_batch_static",
            "dj_set_sweep_path", "dj_route_plan", "dj_route_unique_id", "dj_router_create", "dj_router_destroy",
-           "dj_router_last_error", "dj_route_start", "dj_route_advance", "dj_route_next", "dj_route_release"]
+           "dj_router_last_error", "dj_route_start", "dj_route_advance", "dj_route_next", "dj_route_release",
+           "dj_complete_one", "dj_update_metadata_one", "dj_store_nearest_in_publish_queue", "dj_unprocessed"]
 # include/dj_batcher.h
 BATCHER_SYMBOLS = ["dj_batcher_create", "dj_batcher_destroy", "dj_batcher_set_clock", "dj_batcher_join",
                    "dj_batcher_fork", "dj_batcher_join_wait", "dj_batcher_fork_wait", "dj_batcher_run",
@@ -134,6 +136,15 @@ def load():
     L.dj_snapshot_one.argtypes = [vp, u64, u64, i32, vp, vp, vp, vp]
     L.dj_store_in_publish_queue.restype = i32
     L.dj_store_in_publish_queue.argtypes = [vp, u64, u64, u64]
+    if not os.environ.get("DJ_ENGINE_LIB") or hasattr(L, "dj_complete_one"):
+        L.dj_complete_one.restype = i32
+        L.dj_complete_one.argtypes = [vp, u64, u64, ctypes.POINTER(ctypes.c_int32)]
+        L.dj_update_metadata_one.restype = i32
+        L.dj_update_metadata_one.argtypes = [vp, vp, ctypes.POINTER(ctypes.c_int32)]
+        L.dj_store_nearest_in_publish_queue.restype = i32
+        L.dj_store_nearest_in_publish_queue.argtypes = [vp, u64, u64, u64, ctypes.POINTER(ctypes.c_int32)]
+        L.dj_unprocessed.restype = i32
+        L.dj_unprocessed.argtypes = [vp, u64, u32, vp, vp, vp]
     L.dj_queue_scores.restype = i32
     L.dj_queue_scores.argtypes = [vp, u64, u64, ctypes.POINTER(u64), ctypes.POINTER(u64)]
     L.dj_get_stats.restype = i32

@@ -774,7 +774,7 @@ extern "C" int dj_ack_batch(dj_engine* e, uint32_t n, const uint32_t* d_n, const
     if (n == 0) return DJ_OK;
     if (!d_conts || !d_status) return fail(e, DJ_E_INVALID, "ack: null pointer");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
-    LAUNCH(e, DJ_PROF_ACK, (ack_kernel<<<grid_for(n, ACK_BLOCK), ACK_BLOCK, 0, e->stream>>>(e->t, n, d_n, d_conts, d_ok, now_ms, d_status)));
+    LAUNCH(e, DJ_PROF_ACK, (ack_kernel<false><<<grid_for(n, ACK_BLOCK), ACK_BLOCK, 0, e->stream>>>(e->t, n, d_n, d_conts, d_ok, now_ms, d_status)));
     HIP_TRY(e, hipGetLastError());
     return DJ_OK;
 }
@@ -853,6 +853,77 @@ extern "C" int dj_queue_scores(dj_engine* e, uint64_t fp_lo, uint64_t fp_hi, uin
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     if (h_primary_at) *h_primary_at = sc[0];
     if (h_backup_at) *h_backup_at = sc[1];
+    return DJ_OK;
+}
+
+// One row through the command form of the ack pass (redis/complete or redis/update-metadata alone).
+static int command_one(dj_engine* e, uint8_t op, const dj_cont& row, int32_t* h_status) {
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    // staging: the row in d_one_cont, the command byte in the first of the two score words, the answer in the second
+    uint64_t words[2] = {op, 0};
+    HIP_TRY(e, hipMemcpyAsync(e->d_one_cont, &row, sizeof row, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->d_one_scores, words, sizeof words, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));       // row and words live on this thread's stack
+    ack_kernel<true><<<1, ACK_BLOCK, 0, e->stream>>>(e->t, 1, nullptr, e->d_one_cont, reinterpret_cast<const uint8_t*>(e->d_one_scores),
+                                                     0, reinterpret_cast<int32_t*>(e->d_one_scores + 1));
+    HIP_TRY(e, hipGetLastError());
+    int32_t st = 0;
+    HIP_TRY(e, hipMemcpyAsync(&st, e->d_one_scores + 1, 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    *h_status = st;
+    return DJ_OK;
+}
+
+extern "C" int dj_complete_one(dj_engine* e, uint64_t fp_lo, uint64_t fp_hi, int32_t* h_status) {
+    if (!e || !h_status) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
+    dj_cont row = {};
+    row.fp_lo = fp_lo;
+    row.fp_hi = fp_hi;
+    return command_one(e, ACK_OP_COMPLETE, row, h_status);
+}
+
+extern "C" int dj_update_metadata_one(dj_engine* e, const dj_cont* h_meta, int32_t* h_status) {
+    if (!e || !h_meta || !h_status) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
+    dj_cont row = {};
+    row.fp_lo = h_meta->fp_lo;
+    row.fp_hi = h_meta->fp_hi;
+    row.count = h_meta->count;
+    row.deadline_ms = h_meta->deadline_ms;
+    row.retry_publish = h_meta->retry_publish;
+    row.retry_timeout = h_meta->retry_timeout;
+    return command_one(e, ACK_OP_SET_METADATA, row, h_status);
+}
+
+extern "C" int dj_store_nearest_in_publish_queue(dj_engine* e, uint64_t fp_lo, uint64_t fp_hi, uint64_t at_ms, int32_t* h_result) {
+    if (!e || !h_result) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
+    if (!clock_ok(at_ms)) return fail(e, DJ_E_CLOCK_RANGE, "store_nearest_in_publish_queue: at_ms outside [1e12, 9e12)");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    store_nearest_one_kernel<<<1, 64, 0, e->stream>>>(e->t, fp_lo, fp_hi, at_ms, e->d_one_err);
+    HIP_TRY(e, hipGetLastError());
+    HIP_TRY(e, hipMemcpyAsync(h_result, e->d_one_err, 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return DJ_OK;
+}
+
+extern "C" int dj_unprocessed(dj_engine* e, uint64_t now_ms, uint32_t cap, dj_cont* d_conts, dj_sweep_result* d_result,
+                              dj_sweep_result* h_result) {
+    if (!e) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
+    if (!clock_ok(now_ms)) return fail(e, DJ_E_CLOCK_RANGE, "unprocessed: now_ms=%llu outside [1e12, 9e12)", (unsigned long long)now_ms);
+    if (!d_conts || cap == 0) return fail(e, DJ_E_INVALID, "unprocessed: no output buffer");
+    dj_sweep_result* res = d_result ? d_result : e->d_result;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipMemsetAsync(res, 0, sizeof(dj_sweep_result), e->stream));
+    list_unprocessed_kernel<<<scan_blocks(e), 256, 0, e->stream>>>(e->t, now_ms - e->cfg.check_publish_delay_ms, cap, d_conts, res);
+    clamp_count_kernel<<<1, 64, 0, e->stream>>>(res, cap);
+    HIP_TRY(e, hipGetLastError());
+    if (h_result) {
+        HIP_TRY(e, hipMemcpyAsync(h_result, res, sizeof(dj_sweep_result), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(e, hipStreamSynchronize(e->stream));
+    }
     return DJ_OK;
 }
 

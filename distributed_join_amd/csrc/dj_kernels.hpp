@@ -1551,9 +1551,10 @@ gather_kernel(Table t, Work w, const dj_cont* conts, int from_sweep,
 // core/complete on a slot this thread owns: redis/complete (Lua, redis.clj:177-188) and on
 // "Join Updated" reset-publish.  Returns true when the barrier is to be deleted; the caller
 // then frees the slab (wave-cooperatively) and clears the slot.
-__device__ inline bool complete_decide(const Table& t, uint64_t s, uint64_t now) {
+__device__ inline bool complete_decide(const Table& t, uint64_t s, uint64_t now, bool reset = true) {
     Slot* sl = &t.slots[s];
     if (sl->join_ts == sl->join_ts_read) return true;          // two nils compare equal
+    if (!reset) return false;                                  // redis/complete alone: the Lua error reply, nothing written
     // reset-publish: both retry counters dropped, :publish-retry-cnt 0, re-queued at now
     sl->meta = meta_pack(sl->meta & META_HAS, 0, RETRY_NIL) | (sl->meta & META_KEEP);
     t.q[s] = now;
@@ -1581,6 +1582,14 @@ __device__ inline void retry_requeue(const Table& t, uint64_t s, bool timeout, u
 
 constexpr int ACK_BLOCK = 512;
 
+// CMD = false: the publisher's outcome per continuation, ok[i] != 0 = the POST succeeded.
+// CMD = true (the single-key store commands of the host, one row per launch): ok[i] is a command,
+//   0 / 1 as above, ACK_OP_COMPLETE = redis/complete alone (redis.clj:191-205: delete, or answer DJ_ACK_DIRTY and
+//   write nothing), ACK_OP_SET_METADATA = redis/update-metadata alone (redis.clj:106-111: the row is the metadata
+//   map, written as it is: no counter is raised, no queue is touched).
+constexpr uint8_t ACK_OP_COMPLETE = 2, ACK_OP_SET_METADATA = 3;
+
+template <bool CMD>
 __global__ void __launch_bounds__(ACK_BLOCK) ack_kernel(Table t, uint32_t n_max, const uint32_t* d_n, const dj_cont* conts,
                                                         const uint8_t* ok, uint64_t now, int32_t* status) {
     __shared__ uint32_t lds[BLOCK_SLAB_LDS];
@@ -1601,15 +1610,17 @@ __global__ void __launch_bounds__(ACK_BLOCK) ack_kernel(Table t, uint32_t n_max,
     if (live) c = conts[i];
     // a row that no sweep of this engine can have written (a snapshot with metadata whose :count is outside
     // 1..max_count): answered 0 like a void row, nothing changes
-    const bool sane = (c.flags & DJ_CONT_NO_METADATA) || (c.count >= 1 && c.count <= t.max_count);
+    const uint8_t op = CMD && live && ok ? ok[i] : 0;
+    const bool only_complete = CMD && op == ACK_OP_COMPLETE, only_set = CMD && op == ACK_OP_SET_METADATA;
+    const bool sane = only_complete || (!only_set && (c.flags & DJ_CONT_NO_METADATA)) || (c.count >= 1 && c.count <= t.max_count);
     if (live && !(c.flags & CONT_VOID) && sane) {
         const bool published = ok == nullptr || ok[i] != 0;
-        const bool has_md = !(c.flags & DJ_CONT_NO_METADATA);
+        const bool has_md = only_complete || only_set || !(c.flags & DJ_CONT_NO_METADATA);
         rp = retry_from_api(c.retry_publish);
         rt = retry_from_api(c.retry_timeout);
-        bool complete_path = !has_md || published;     // core.clj:159-161 / 134-136 (no metadata), core.clj:168 (published)
+        bool complete_path = !only_set && (!has_md || published);     // core.clj:159-161 / 134-136 (no metadata), core.clj:168 (published)
         int32_t deleted_code = has_md ? DJ_ACK_DONE : DJ_ACK_DONE_NO_METADATA;
-        if (!complete_path && !retries_left(t, c.deadline_ms, rp, rt, now, &timeout, &cnt)) {
+        if (!complete_path && !only_set && !retries_left(t, c.deadline_ms, rp, rt, now, &timeout, &cnt)) {
             complete_path = true;                      // core.clj:142-147: retries exhausted
             deleted_code = DJ_ACK_DROPPED_EXHAUSTED;
         }
@@ -1622,7 +1633,7 @@ __global__ void __launch_bounds__(ACK_BLOCK) ack_kernel(Table t, uint32_t n_max,
             if (s < 0) s = find_slot(t, c.fp_lo, c.fp_hi);
             if (s < 0) {
                 st = deleted_code;                     // nothing left to delete
-            } else if (complete_decide(t, (uint64_t)s, now)) {
+            } else if (complete_decide(t, (uint64_t)s, now, !only_complete)) {
                 st = deleted_code;
                 clear = true;
                 s_u = (uint64_t)s;
@@ -1635,7 +1646,7 @@ __global__ void __launch_bounds__(ACK_BLOCK) ack_kernel(Table t, uint32_t n_max,
                     rel_to = (m & META_KX_MASK) ? class_positions(k_old) : t.slots[s].count;
                 }
             } else {
-                st = DJ_ACK_REQUEUED_DIRTY;
+                st = only_complete ? DJ_ACK_DIRTY : DJ_ACK_REQUEUED_DIRTY;
             }
         } else {
             // publish failed, retries left: update-metadata writes the publisher's snapshot back
@@ -1718,9 +1729,10 @@ __global__ void __launch_bounds__(ACK_BLOCK) ack_kernel(Table t, uint32_t n_max,
         }
         if (set_count) sl->count = c.count;
         sl->deadline = c.deadline_ms;
-        retry_requeue(t, s_u, timeout, cnt, rp, rt, now);                  // core.clj:151
+        if (only_set) sl->meta = meta_pack(true, rp, rt) | (sl->meta & META_KEEP);      // SET <id>:metadata, redis.clj:110
+        else retry_requeue(t, s_u, timeout, cnt, rp, rt, now);             // core.clj:151
         sl->meta = (sl->meta & ~META_KX_MASK) | (kx_new << META_KX_SHIFT);
-        st = DJ_ACK_RETRY;
+        st = only_set ? DJ_ACK_METADATA_SET : DJ_ACK_RETRY;
     }
     if (live) status[i] = st;
 }
@@ -1858,6 +1870,38 @@ __global__ void store_in_queue_one_kernel(Table t, uint64_t lo, uint64_t hi, uin
     t.q[s] = at;
     note_queue_date(t, (uint64_t)s, at);
     *err = 0;
+}
+
+// redis/store-nearest-in-publish-queue for one id (Lua, redis.clj:261-281): ZSCORE of the primary queue; a member
+// that is not there makes the script's comparison raise (*out = -1); a later date than `at` moves both queues'
+// entries to `at`.  The script's answer is ZADD's count of NEW members, 0 either way (*out = 0).
+__global__ void store_nearest_one_kernel(Table t, uint64_t lo, uint64_t hi, uint64_t at, int32_t* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int64_t s = find_slot(t, lo, hi);
+    const uint64_t pa = s < 0 ? NQ : q_primary_at(t.q[s]);
+    if (pa == NQ) { *out = -1; return; }
+    if (pa > at) {
+        t.q[s] = at;
+        note_queue_date(t, (uint64_t)s, at);
+    }
+    *out = 0;
+}
+
+// redis/get-unprocessed-publish-messages (redis.clj:291-293): every member of the backup queue with a score of at
+// most max_score, described as a continuation (fingerprint, metadata, publish_at = the backup score).  Read-only.
+__global__ void __launch_bounds__(256) list_unprocessed_kernel(Table t, uint64_t max_score, uint32_t cap, dj_cont* conts,
+                                                               dj_sweep_result* res) {
+    const uint64_t nslots = t.mask + 1;
+    for (uint64_t s0 = (uint64_t)blockIdx.x * blockDim.x; s0 < nslots; s0 += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t s = s0 + threadIdx.x;       // slots are a multiple of the block size: whole waves iterate together
+        const uint64_t qv = t.q[s];
+        const uint64_t ba = q_backup_at(qv);
+        const bool due = qv != Q_NONE && ba <= max_score;
+        const uint32_t at = wave_append(&res->n_conts, due);
+        if (!due) continue;
+        if (at < cap) fill_cont(&conts[at], t.slots[s], 0, ba, 0, s + 1);
+        else res->more = 1;
+    }
 }
 
 // Table hygiene: deleted barriers leave tombstones, and a lookup of an absent key only stops at a

@@ -276,6 +276,38 @@ class Engine:
         self._check(self.L.dj_queue_scores(self.h, int(fp_lo), int(fp_hi), ctypes.byref(a), ctypes.byref(b)))
         return a.value, b.value
 
+    # ---- the store namespace's remaining commands, one key at a time ------------------------------
+    def complete_one(self, fp_lo, fp_hi):
+        """redis/complete alone -> DJ_ACK_DONE (deleted) or DJ_ACK_DIRTY (a join arrived since the last all-joins)."""
+        st = ctypes.c_int32(0)
+        self._check(self.L.dj_complete_one(self.h, int(fp_lo), int(fp_hi), ctypes.byref(st)))
+        return st.value
+
+    def update_metadata_one(self, fp_lo, fp_hi, count, deadline_ms, retry_publish=None, retry_timeout=None):
+        """redis/update-metadata alone: SET of the metadata map -> DJ_ACK_METADATA_SET, or 0 when refused."""
+        row = np.zeros(1, dtype=CONT)
+        row[0]["fp_lo"], row[0]["fp_hi"], row[0]["count"], row[0]["deadline_ms"] = fp_lo, fp_hi, count, deadline_ms
+        row[0]["retry_publish"] = capi.DJ_NIL if retry_publish is None else retry_publish
+        row[0]["retry_timeout"] = capi.DJ_NIL if retry_timeout is None else retry_timeout
+        st = ctypes.c_int32(0)
+        self._check(self.L.dj_update_metadata_one(self.h, row.ctypes.data_as(ctypes.c_void_p), ctypes.byref(st)))
+        return st.value
+
+    def store_nearest_in_publish_queue(self, fp_lo, fp_hi, at_ms):
+        """redis/store-nearest-in-publish-queue -> 0, or -1 when the id is not in the primary queue (the Lua error)."""
+        out = ctypes.c_int32(0)
+        self._check(self.L.dj_store_nearest_in_publish_queue(self.h, int(fp_lo), int(fp_hi), int(at_ms), ctypes.byref(out)))
+        return out.value
+
+    def unprocessed(self, now_ms):
+        """redis/get-unprocessed-publish-messages -> (conts[CONT], more); read-only."""
+        b = self._bufs()
+        res = np.zeros(1, dtype=SWEEP_RESULT)
+        self._check(self.L.dj_unprocessed(self.h, int(now_ms), self.host_cap_conts, b["conts"].data_ptr(), b["res"].data_ptr(),
+                                          res.ctypes.data_as(ctypes.c_void_p)))
+        n = int(res[0]["n_conts"])
+        return from_device(b["conts"][: max(n, 1) * CONT.itemsize], CONT, n), bool(res[0]["more"])
+
     def set_hot_path(self, mode):
         """-1 automatic, 0 serial, 1 parallel kernels for barriers with long chains; +2 pins the 16-event
         register replay of short chains, 0 / 1 the 8-event one; +4 keeps the separate message-copy pass where

@@ -82,6 +82,10 @@ typedef struct dj_engine dj_engine;
 #define DJ_ACK_RETRY                3  /* retry counter +1, re-queued at now        core.clj:148-152 */
 #define DJ_ACK_DROPPED_EXHAUSTED    4  /* retries exhausted, barrier deleted        core.clj:142-147 */
 #define DJ_ACK_DONE_NO_METADATA     5  /* metadata was missing: completed as failed core.clj:134-136,159-161 */
+/* the single-key store commands below (dj_complete_one, dj_update_metadata_one) */
+#define DJ_ACK_DIRTY                6  /* redis/complete alone: a join arrived after the snapshot; the Lua script
+                                          answers its error and changes nothing             redis.clj:186-187 */
+#define DJ_ACK_METADATA_SET         7  /* redis/update-metadata wrote the map               redis.clj:106-111 */
 
 /* ---- records ------------------------------------------------------------------- */
 
@@ -263,6 +267,37 @@ int dj_store_in_publish_queue(dj_engine* e, uint64_t fp_lo, uint64_t fp_hi, uint
 /* redis/get-publish-date (redis.clj:295-297) and the backup score: DJ_NOT_QUEUED when absent. */
 int dj_queue_scores(dj_engine* e, uint64_t fp_lo, uint64_t fp_hi,
                     uint64_t* h_primary_at, uint64_t* h_backup_at);
+
+/* ---- the remaining commands of the store namespace, one key at a time ----------------------------
+ * With these, every public function of distributed-join.redis (redis.clj:90-300) has an entry point of its own,
+ * so a host can keep core.clj as it is and replace only the namespace behind it (INTEGRATION.md lists the
+ * thirteen).  The batch calls above fuse what core.clj does between two of these commands; these do not. */
+
+/* redis/complete (redis.clj:191-205, Lua complete-if-no-update redis.clj:162-189): deletes the barrier (metadata,
+ * messages, both timestamps, both queue entries) when no join arrived since the last redis/all-joins, else
+ * changes nothing.  *h_status = DJ_ACK_DONE or DJ_ACK_DIRTY (the error deferred that carries
+ * :updated-join-before-complete, redis.clj:203-205). */
+int dj_complete_one(dj_engine* e, uint64_t fp_lo, uint64_t fp_hi, int32_t* h_status);
+
+/* redis/update-metadata (redis.clj:106-111): SET of the metadata map held in *h_meta (fp_lo, fp_hi, count,
+ * deadline_ms = :timeout-secs, retry_publish, retry_timeout with DJ_NIL = key absent; the other fields are
+ * ignored).  Creates the metadata when the barrier has none; stored messages and queue entries stay as they are
+ * (a count that differs from the live one is handled as dj_ack_batch's failed publish handles it).
+ * *h_status = DJ_ACK_METADATA_SET, or 0 when nothing was written (count outside 1..max_count, table full). */
+int dj_update_metadata_one(dj_engine* e, const dj_cont* h_meta, int32_t* h_status);
+
+/* redis/store-nearest-in-publish-queue (redis.clj:277-281, Lua redis.clj:261-275): when the id's primary-queue
+ * score is later than at_ms, both queues' entries move to at_ms.  *h_result = 0 (the script's answer: ZADD adds no
+ * new member either way), or -1 when the id is not in the primary queue (the script's comparison of a nil score
+ * raises; the reference's caller gets an error deferred). */
+int dj_store_nearest_in_publish_queue(dj_engine* e, uint64_t fp_lo, uint64_t fp_hi, uint64_t at_ms, int32_t* h_result);
+
+/* redis/get-unprocessed-publish-messages (redis.clj:291-293): the members of the backup queue with a score of at
+ * most now_ms - check_publish_delay_ms, at most cap of them (d_result->more tells whether some were left out),
+ * each described by a dj_cont (fingerprint, metadata snapshot, publish_at = the backup score).  Read-only; order
+ * unspecified (Redis' is by score, then member bytes).  h_result (optional) makes the call synchronous. */
+int dj_unprocessed(dj_engine* e, uint64_t now_ms, uint32_t cap, dj_cont* d_conts,
+                   dj_sweep_result* d_result, dj_sweep_result* h_result);
 
 /* table occupancy, for monitoring and tests */
 typedef struct dj_stats {

@@ -462,4 +462,50 @@ void djo_queue_scores(djo* o, uint32_t id_idx, uint64_t* primary_at, uint64_t* b
 
 uint64_t djo_live_barriers(djo* o) { return o->metadata.size(); }
 
+// ---- the store namespace command by command (redis.clj's public functions, nothing of core.clj) ----
+namespace {
+Metadata md_from(uint32_t count, uint64_t timeout_secs, uint32_t retry_publish, uint32_t retry_timeout) {
+    Metadata m;
+    m.count = count;
+    m.timeout_secs = timeout_secs;
+    if (retry_publish != DJO_NIL) m.publish_retry_cnt = retry_publish;
+    if (retry_timeout != DJO_NIL) m.timeout_publish_retry_cnt = retry_timeout;
+    return m;
+}
+int64_t ids_out(djo* o, const std::vector<string>& v, uint32_t cap, uint32_t* id_idx) {
+    if (v.size() > cap) return -1;
+    for (size_t k = 0; k < v.size(); ++k) id_idx[k] = o->idx_of(v[k]);
+    return (int64_t)v.size();
+}
+}  // namespace
+
+void djo_redis_fork(djo* o, uint32_t id_idx, uint32_t count, uint64_t timeout_secs) {
+    o->redis_fork(o->id_of(id_idx), md_from(count, timeout_secs, DJO_NIL, DJO_NIL));
+}
+void djo_redis_update_metadata(djo* o, uint32_t id_idx, uint32_t count, uint64_t timeout_secs, uint32_t retry_publish,
+                               uint32_t retry_timeout) {
+    o->redis_update_metadata(o->id_of(id_idx), md_from(count, timeout_secs, retry_publish, retry_timeout));
+}
+int djo_redis_join(djo* o, uint32_t id_idx, uint32_t position, const uint8_t* message, uint32_t len,
+                   uint32_t max_wait_s, uint64_t now_ms, uint32_t* hlen) {
+    JoinRecord r;
+    r.message.assign((const char*)message, len);
+    if (max_wait_s) r.max_wait = max_wait_s;
+    Metadata md;
+    return o->redis_join(o->id_of(id_idx), position, r, now_ms, &md, hlen);
+}
+int djo_redis_complete(djo* o, uint32_t id_idx) {
+    return o->redis_complete(o->id_of(id_idx)) == CompleteResult::Deleted ? 1 : 0;
+}
+int djo_redis_store_nearest_in_publish_queue(djo* o, uint32_t id_idx, uint64_t publish_at) {
+    return o->redis_store_nearest_in_publish_queue(o->id_of(id_idx), publish_at) ? 1 : 0;
+}
+int64_t djo_redis_all_publish_messages(djo* o, uint64_t now_ms, uint32_t cap, uint32_t* id_idx) {
+    if (o->publish_queue.zrangebyscore(now_ms).size() > cap) return -1;
+    return ids_out(o, o->redis_all_publish_messages(now_ms), cap, id_idx);
+}
+int64_t djo_redis_get_unprocessed_publish_messages(djo* o, uint64_t now_ms, uint32_t cap, uint32_t* id_idx) {
+    return ids_out(o, o->redis_get_unprocessed_publish_messages(now_ms), cap, id_idx);
+}
+
 }  // extern "C"

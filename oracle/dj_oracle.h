@@ -82,6 +82,22 @@ void djo_store_in_publish_queue(djo* o, uint32_t id_idx, uint64_t at_ms);
 void djo_queue_scores(djo* o, uint32_t id_idx, uint64_t* primary_at, uint64_t* backup_at);
 uint64_t djo_live_barriers(djo* o);
 
+/* The public functions of redis.clj one by one (no core.clj logic around them): what a host that keeps
+ * core.clj and replaces only the namespace calls.  redis/join-metadata, all-joins, all-joins-status,
+ * store-in-publish-queue and get-publish-date are djo_snapshot_one, djo_store_in_publish_queue and
+ * djo_queue_scores above. */
+void djo_redis_fork(djo* o, uint32_t id_idx, uint32_t count, uint64_t timeout_secs);                  /* redis.clj:90-104 */
+void djo_redis_update_metadata(djo* o, uint32_t id_idx, uint32_t count, uint64_t timeout_secs,
+                               uint32_t retry_publish, uint32_t retry_timeout);                      /* redis.clj:106-111 */
+/* 0 with *hlen = HLEN, or DJO_JOIN_NOT_FOUND / DJO_JOIN_BAD_POSITION                                   redis.clj:143-159 */
+int djo_redis_join(djo* o, uint32_t id_idx, uint32_t position, const uint8_t* message, uint32_t len,
+                   uint32_t max_wait_s, uint64_t now_ms, uint32_t* hlen);
+int djo_redis_complete(djo* o, uint32_t id_idx);            /* 1 deleted, 0 "Join Updated" error        redis.clj:191-205 */
+int djo_redis_store_nearest_in_publish_queue(djo* o, uint32_t id_idx, uint64_t publish_at);   /* 1, or 0: the script raised, redis.clj:261-281 */
+/* ids in (score, member) order; -1 when cap is too small (nothing popped then)                         redis.clj:283-293 */
+int64_t djo_redis_all_publish_messages(djo* o, uint64_t now_ms, uint32_t cap, uint32_t* id_idx);
+int64_t djo_redis_get_unprocessed_publish_messages(djo* o, uint64_t now_ms, uint32_t cap, uint32_t* id_idx);
+
 #ifdef __cplusplus
 }
 #endif

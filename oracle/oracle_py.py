@@ -56,6 +56,18 @@ def _load():
     lib.djo_queue_scores.argtypes = [vp, u32, vp, vp]
     lib.djo_live_barriers.restype = u64
     lib.djo_live_barriers.argtypes = [vp]
+    lib.djo_redis_fork.argtypes = [vp, u32, u32, u64]
+    lib.djo_redis_update_metadata.argtypes = [vp, u32, u32, u64, u32, u32]
+    lib.djo_redis_join.restype = ctypes.c_int
+    lib.djo_redis_join.argtypes = [vp, u32, u32, ctypes.c_char_p, u32, u32, u64, ctypes.POINTER(u32)]
+    lib.djo_redis_complete.restype = ctypes.c_int
+    lib.djo_redis_complete.argtypes = [vp, u32]
+    lib.djo_redis_store_nearest_in_publish_queue.restype = ctypes.c_int
+    lib.djo_redis_store_nearest_in_publish_queue.argtypes = [vp, u32, u64]
+    lib.djo_redis_all_publish_messages.restype = i64
+    lib.djo_redis_all_publish_messages.argtypes = [vp, u64, u32, vp]
+    lib.djo_redis_get_unprocessed_publish_messages.restype = i64
+    lib.djo_redis_get_unprocessed_publish_messages.argtypes = [vp, u64, u32, vp]
     return lib
 
 
@@ -265,3 +277,122 @@ class OracleStore:
     def queue_scores(self, barrier_id):
         a, b = self.o.queue_scores(self._idx(barrier_id))
         return (None if a == NOT_QUEUED else a, None if b == NOT_QUEUED else b)
+
+
+class OracleRedis:
+    """The namespace distributed-join.redis on the checker, function for function (redis.clj:90-300): the same
+    thirteen functions, arguments, return shapes and failures as distributed_join_amd.redis_namespace.EngineRedis,
+    each on the oracle's restatement of that one Redis command sequence.  core_unchanged.Core runs on either."""
+
+    def __init__(self, oracle, clock, env):
+        from distributed_join_amd import redis_namespace as ns
+        self.ns = ns
+        self.o = oracle
+        self.clock = clock
+        self.env = env
+        self.records = {}       # the strings of "<id>:metadata" (ids, URLs); numbers live in the oracle
+
+    def _idx(self, barrier_id):
+        b = barrier_id.encode()
+        if b not in self.o.index:
+            self.o.set_ids([i.decode() for i in self.o.ids] + [barrier_id])
+        return self.o.index[b]
+
+    def _ids(self, fn, now):
+        out = np.zeros(1 << 16, dtype=np.uint32)
+        n = fn(self.o.h, int(now), len(out), _p(out))
+        if n < 0:
+            raise RuntimeError("oracle: id buffer too small")
+        return [self.o.ids[int(k)].decode() for k in out[:n]]
+
+    @staticmethod
+    def _strings(m):
+        return {k: v for k, v in m.items() if k not in ("publish-retry-cnt", "timeout-publish-retry-cnt")}
+
+    def fork(self, record):
+        key = self.ns.make_key(record["join-id"], record["transaction-id"])
+        self.o.L.djo_redis_fork(self.o.h, self._idx(key), record["count"], record["timeout-secs"])
+        self.records[key] = self._strings(record)
+        return key
+
+    def update_metadata(self, metadata):
+        key = self.ns.make_key(metadata.get("join-id"), metadata.get("transaction-id"))
+        opt = lambda v: NIL if v is None else v
+        self.o.L.djo_redis_update_metadata(self.o.h, self._idx(key), metadata["count"], metadata["timeout-secs"],
+                                           opt(metadata.get("publish-retry-cnt")), opt(metadata.get("timeout-publish-retry-cnt")))
+        self.records[key] = self._strings(metadata)
+        return key + ":metadata"
+
+    def join(self, record):
+        bid = record["barrier-id"]
+        md = self.join_metadata(bid)                                       # GET, redis.clj:149
+        msg = record["message"].encode()
+        hlen = ctypes.c_uint32(0)
+        st = self.o.L.djo_redis_join(self.o.h, self._idx(bid), min(record["position"], 0xFFFFFFFF), msg, len(msg),
+                                     record.get("max-wait") or 0, int(self.clock()), ctypes.byref(hlen))
+        if st == 3:
+            raise self.ns.err("not-found", "barrier-id does not exist")
+        if st == 4:
+            raise self.ns.err("bad-data", "position is greater than total")
+        return {"metadata": md, "count": hlen.value}
+
+    def complete(self, barrier_id):
+        if not self.o.L.djo_redis_complete(self.o.h, self._idx(barrier_id)):
+            raise self.ns.StoreError("Join was updated before fork could be completed", {"updated-join-before-complete": True})
+        self.records.pop(barrier_id, None)
+        return 1
+
+    def _all_joins(self, barrier_id, count, update_ts):
+        meta, lens, mws, pay = self.o.snapshot_one(self._idx(barrier_id), update_ts)
+        if count is None:
+            return None
+        out = []
+        for p in range(count):
+            if p >= len(lens) or int(lens[p]) == NIL:
+                out.append(None)
+                continue
+            j = {"barrier-id": barrier_id, "position": p, "message": bytes(pay[p, :int(lens[p])]).decode()}
+            if int(mws[p]):
+                j["max-wait"] = int(mws[p])
+            out.append(j)
+        return out
+
+    def all_joins(self, barrier_id, count):
+        return self._all_joins(barrier_id, count, True)
+
+    def all_joins_status(self, barrier_id, count):
+        return self._all_joins(barrier_id, count, False)
+
+    def join_metadata(self, barrier_id):
+        meta = np.zeros(1, dtype=OCONT)
+        self.o.L.djo_snapshot_one(self.o.h, self._idx(barrier_id), 0, _p(meta), None, None, None, self.o.stride)
+        if int(meta[0]["flags"]) & 2:
+            return None
+        md = dict(self.records.get(barrier_id, {}))
+        md["count"], md["timeout-secs"] = int(meta[0]["count"]), int(meta[0]["deadline_ms"])
+        for key, field in (("publish-retry-cnt", "retry_publish"), ("timeout-publish-retry-cnt", "retry_timeout")):
+            if int(meta[0][field]) != NIL:
+                md[key] = int(meta[0][field])
+        return md
+
+    def store_in_publish_queue(self, barrier_id, publish_at):
+        self.o.store_in_publish_queue(self._idx(barrier_id), publish_at)
+        return [publish_at]
+
+    def store_nearest_in_publish_queue(self, barrier_id, publish_at):
+        if not self.o.L.djo_redis_store_nearest_in_publish_queue(self.o.h, self._idx(barrier_id), int(publish_at)):
+            raise self.ns.database_failure("attempt to compare boolean with string")
+        return [publish_at, 0]
+
+    def all_publish_messages(self):
+        return self._ids(self.o.L.djo_redis_all_publish_messages, self.clock())
+
+    def get_unprocessed_publish_messages(self):
+        return self._ids(self.o.L.djo_redis_get_unprocessed_publish_messages, self.clock())
+
+    def get_publish_date(self, barrier_id):
+        a, _ = self.o.queue_scores(self._idx(barrier_id))
+        return None if a == NOT_QUEUED else a
+
+    def shutdown(self):
+        self.o.close()

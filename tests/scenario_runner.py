@@ -44,13 +44,17 @@ class FakeDestination:
         return {"status": 201}
 
 
-def run_scenario(sc, t0, make_store):
-    """make_store(env) -> store object (EngineStore or OracleStore)."""
+def run_scenario(sc, t0, make_store, make_service=ForkJoinService):
+    """make_store(env) or make_store(env, clock) -> store object (EngineStore or OracleStore, or a namespace view
+    from tests/namespace_view.py); make_service(store, clock, post, env=env) -> the request logic over it."""
     env = sc["env"]
     clock = [t0]
     dest = FakeDestination()
-    store = make_store(env)
-    svc = ForkJoinService(store, lambda: clock[0], dest.post, env=env)
+    try:
+        store = make_store(env, lambda: clock[0])
+    except TypeError:
+        store = make_store(env)
+    svc = make_service(store, lambda: clock[0], dest.post, env=env)
 
     def do(step):
         clock[0] = t0 + step["t"]
