@@ -141,3 +141,93 @@ def test_random_request_streams_engine_namespace_against_oracle_namespace(seed, 
     finally:
         for e in engines:
             e.close()
+
+
+def command_stream(seed, n_steps):
+    """Namespace functions called directly, in orders core.clj never produces: metadata written with any count
+    while messages are stored (larger, smaller, for ids that have none), completes at any time, queue dates moved
+    by hand, pops and backup listings in between."""
+    rng = random.Random(1000 + seed)
+    ids = [(f"c{k}", "x") for k in range(5)]
+    t = 0
+    for _ in range(n_steps):
+        t += rng.choice((1, 1, 3, 40, 900, 12000))
+        j, x = rng.choice(ids)
+        bid = f"{j}~{x}"
+        roll = rng.random()
+        if roll < 0.12:
+            yield t, "fork", {"join-id": j, "transaction-id": x, "count": rng.choice((1, 2, 4, 9, 65, 130)),
+                              "destination": "http://d/ok", "max-wait": rng.choice((1, 30, 600))}
+        elif roll < 0.50:
+            req = {"barrier-id": bid, "position": rng.choice((0, 1, 2, 3, 5, 8, 64, 100, 129)), "message": "m%d" % rng.randrange(50)}
+            if rng.random() < 0.25:
+                req["max-wait"] = rng.choice((1, 50))
+            yield t, "join", req
+        elif roll < 0.62:
+            yield t, "update_metadata", {"join-id": j, "transaction-id": x, "count": rng.choice((1, 2, 3, 4, 9, 16, 65, 130, 200)),
+                                         "timeout-secs": T0 + t + rng.choice((-5000, 10, 5000)), "destination": "http://d/ok",
+                                         **({"publish-retry-cnt": rng.randrange(4)} if rng.random() < 0.5 else {}),
+                                         **({"timeout-publish-retry-cnt": rng.randrange(4)} if rng.random() < 0.3 else {})}
+        elif roll < 0.70:
+            yield t, "complete", bid
+        elif roll < 0.78:
+            yield t, "all_joins", bid
+        elif roll < 0.83:
+            yield t, "store_in_publish_queue", (bid, T0 + t + rng.choice((-1, 0, 700)))
+        elif roll < 0.90:
+            yield t, "store_nearest_in_publish_queue", (bid, T0 + t + rng.choice((1, 500, 100000)))
+        elif roll < 0.96:
+            yield t, "all_publish_messages", None
+        else:
+            yield t, "get_unprocessed_publish_messages", None
+
+
+def run_commands(view, seed, n_steps):
+    from distributed_join_amd.redis_namespace import StoreError
+    clock = [T0]
+    r = view.redis
+    r.clock = lambda: clock[0]
+    core = CoreService(view, lambda: clock[0], None, env=r.env).core
+    ids = [f"c{k}~x" for k in range(5)]
+    log = []
+    for t, kind, arg in command_stream(seed, n_steps):
+        clock[0] = T0 + t
+        try:
+            if kind == "fork":
+                out = core.fork(arg)
+            elif kind == "join":
+                out = core.join(arg)
+            elif kind == "all_joins":
+                md = r.join_metadata(arg)
+                out = r.all_joins(arg, md["count"] if md else None)
+            elif isinstance(arg, tuple):
+                out = getattr(r, kind)(*arg)
+            elif arg is None:
+                out = getattr(r, kind)()
+            else:
+                out = getattr(r, kind)(arg)
+        except StoreError as ex:
+            out = ("error", str(ex), sorted(ex.data))
+        # everything a caller could see afterwards
+        state = []
+        for i in ids:
+            md = r.join_metadata(i)
+            state.append((i, md, view.queue_scores(i), None if md is None else r.all_joins_status(i, md["count"])))
+        log.append((kind, arg, out, state))
+    return log
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_namespace_functions_called_directly_against_the_oracle(seed, oracle_lib):
+    from distributed_join_amd.store import DEFAULT_ENV
+    env = dict(DEFAULT_ENV)
+    engines = []
+    try:
+        want = run_commands(oracle_view(oracle_lib, env, None), seed, 300)
+        got = run_commands(engine_view(env, None, engines), seed, 300)
+        for k, (w, g) in enumerate(zip(want, got)):
+            assert w == g, f"seed {seed} step {k}:\noracle {w}\nengine {g}"
+    finally:
+        for e in engines:
+            e.close()
