@@ -389,7 +389,8 @@ join_resolve_kernel(Table t, Work w, uint32_t n, uint64_t now, int32_t* status) 
     uint32_t s = tid < n ? w.ev_slot[tid] : 0xFFFFFFFFu;
     // The event that linked FIRST (it found the chain empty) resolves the barrier: it knows that from
     // its own link word, so every other event leaves without touching the table again.
-    if (s != 0xFFFFFFFFu && node_next(w.node[tid]) != 0) s = 0xFFFFFFFFu;
+    const uint64_t own = s != 0xFFFFFFFFu ? w.node[tid] : 0;
+    if (s != 0xFFFFFFFFu && node_next(own) != 0) s = 0xFFFFFFFFu;
     uint4 info = make_uint4(0, 0, 0, 0);
     uint64_t bits0 = 0;
     if (s != 0xFFFFFFFFu) {
@@ -410,7 +411,7 @@ join_resolve_kernel(Table t, Work w, uint32_t n, uint64_t now, int32_t* status) 
             nd[k] = 0;
             if (cur != 0) {
                 idx[k] = cur - 1;
-                nd[k] = w.node[cur - 1];
+                nd[k] = cur - 1 == tid ? own : w.node[cur - 1];      // every chain ends at this thread's own event
                 cur = node_next(nd[k]);
                 ++m;
             }
