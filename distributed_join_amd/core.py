@@ -20,6 +20,12 @@ class PublishError(Exception):
     """What publish/post raises for a failed or timed-out POST (publish.clj:6-15)."""
 
 
+class PollTimeout(TimeoutError):
+    """core.clj:183-191: one poll of the publisher took longer than :publish-all-complete-timeout-ms.  The
+    reference's deferred/timeout! fails the scheduler's wait and nothing else: the publishes that were under way
+    run to their end, so by the time this is raised every popped barrier has been acked or re-queued."""
+
+
 class ForkJoinService:
     def __init__(self, store, clock, post, env=None):
         self.store = store
@@ -99,7 +105,7 @@ class ForkJoinService:
     # core/process-publish-messages, core.clj:180-191.  Returns None when nothing was due,
     # else one entry per popped barrier: the POST response or the exception it ended with.
     def process_publish_messages(self):
-        now = self.clock()
+        now = started = self.clock()
         conts = self.store.sweep(now)
         if not conts:
             return None
@@ -125,6 +131,8 @@ class ForkJoinService:
             if st in (capi.DJ_ACK_DONE, capi.DJ_ACK_DROPPED_EXHAUSTED, capi.DJ_ACK_DONE_NO_METADATA):
                 self.forks.pop(c.barrier_id, None)
         self.last_ack_statuses = statuses
+        if self.clock() - started > self.env["publish-all-complete-timeout-ms"]:      # core.clj:183-191
+            raise PollTimeout("Timeout while processing publish messages")
         return results
 
     # core/recover-unprocessed-publish-messages, core.clj:193-201

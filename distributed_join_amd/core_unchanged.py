@@ -176,13 +176,18 @@ class Core:
         meta = self.redis.join_metadata(barrier_id)
         return self._publish_message_to_destination(barrier_id, meta, self._select_destination_url(meta))
 
-    # core.clj:180-191 (the 30 s cap of :publish-all-complete-timeout-ms belongs to the scheduler thread)
+    # core.clj:180-191.  deferred/timeout! fails the scheduler's wait after :publish-all-complete-timeout-ms and
+    # cancels nothing: the publishes under way run to their end, then the poll answers with the timeout.
     def process_publish_messages(self):
         self.trace = []
+        started = self.clock()
         ids = self.redis.all_publish_messages()
         if not ids:
             return None
-        return [self._publish_message(i) for i in ids]
+        out = [self._publish_message(i) for i in ids]
+        if self.clock() - started > self.env["publish-all-complete-timeout-ms"]:
+            raise TimeoutError("Timeout while processing publish messages, cancelling all publish messages commands")
+        return out
 
     # core.clj:193-201
     def recover_unprocessed_publish_messages(self):

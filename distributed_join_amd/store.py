@@ -20,6 +20,7 @@ DEFAULT_ENV = {
     "fork-max-wait": 6000,
     "join-max-wait": 6000,
     "check-publish-delay-ms": 10000,
+    "publish-all-complete-timeout-ms": 30000,
     "max-retry-post-publish": 3,
     "max-retry-post-timeout-publish": 3,
     "fork-count-max": 999,

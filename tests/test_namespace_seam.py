@@ -231,3 +231,44 @@ def test_namespace_functions_called_directly_against_the_oracle(seed, oracle_lib
     finally:
         for e in engines:
             e.close()
+
+
+def _poll_that_outlasts_its_cap(make_service, store_or_view, clock):
+    """core.clj:183-191: a poll whose POSTs take longer than :publish-all-complete-timeout-ms ends in a timeout for
+    the scheduler, after every popped barrier was dealt with (completed here: the next poll finds nothing)."""
+    dest = FakeDestination()
+    svc = make_service(store_or_view, lambda: clock[0], dest.post)
+    assert svc.fork({"join-id": "slow", "transaction-id": "1", "count": 1, "destination": "http://d/ok"})[0] == 201
+    assert svc.join({"barrier-id": "slow~1", "position": 0, "message": "m"})[0] == 202
+    dest.hook = lambda: clock.__setitem__(0, clock[0] + 30001)
+    with pytest.raises(TimeoutError):
+        svc.process_publish_messages()
+    assert [r["barrier-id"] for r in dest.requests] == ["slow~1"]
+    dest.hook = None
+    assert svc.process_publish_messages() is None
+    assert svc.status("slow~1")[0] == 404
+
+
+def test_poll_cap_on_the_oracle_at_both_seams(oracle_lib):
+    from distributed_join_amd.core import ForkJoinService
+    from distributed_join_amd.store import DEFAULT_ENV
+    clock = [T0]
+    _poll_that_outlasts_its_cap(CoreService, oracle_view(oracle_lib, dict(DEFAULT_ENV), lambda: clock[0]), clock)
+    clock = [T0]
+    _poll_that_outlasts_its_cap(ForkJoinService, oracle_lib.OracleStore(oracle_lib.Oracle([], max_count=999, payload_stride=256)), clock)
+
+
+@pytest.mark.gpu
+def test_poll_cap_on_the_engine_at_both_seams():
+    from distributed_join_amd.core import ForkJoinService
+    from distributed_join_amd.store import DEFAULT_ENV, EngineStore
+    engines = []
+    try:
+        clock = [T0]
+        _poll_that_outlasts_its_cap(CoreService, engine_view(dict(DEFAULT_ENV), lambda: clock[0], engines), clock)
+        clock = [T0]
+        view = engine_view(dict(DEFAULT_ENV), None, engines)
+        _poll_that_outlasts_its_cap(ForkJoinService, EngineStore(view.redis.e), clock)
+    finally:
+        for e in engines:
+            e.close()
