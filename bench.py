@@ -252,12 +252,17 @@ def run_config3(torch, capi, Engine, dev, local, nb):
     eng.profile_enable(False)
     kern = {name: {"avg_ms": round(sum(v) / len(v), 4), "launches": len(v), "total_ms": round(sum(v), 3)} for name, v in acc.items()}
     n_timeout = int(expire.sum())
+    # the join kernels of this job against their per-event figure 112 + 2P, as roofline.join_path does for configs[1]
+    jt = sum(kern[k]["total_ms"] for k in ("join_link", "join_resolve", "join_complex", "join_copy") if k in kern)
+    jp = {"alg_bytes_per_event": 112 + 2 * P, "ms_per_job": round(jt, 3),
+          "achieved_GBps": round((112 + 2 * P) * n_events / (jt * 1e-3) / 1e9, 1) if jt else None,
+          "frac": round((112 + 2 * P) * n_events / (jt * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if jt else None}
     out = {"workload": f"configs[2]: {nb} barriers, counts Zipf(1) on [2, 64] ({cells} positions), 30 % ({n_timeout}) expire "
                        f"through the timeout sweep with a strict subset of their positions, {P} B messages, {n_batches} batches "
                        f"of {batch} joins + sweep/gather + ack each, clock +2 ms per batch, fork of all barriers included",
            "value": n_events / dt, "unit": "join events/s", "join_events": n_events, "job_ms": dt * 1e3,
            "continuations_per_s": nb / dt, "continuations_fired": fired, "complete": nb - n_timeout, "timeout": n_timeout,
-           "sweeps": sweeps, "table_slots": slots_pow2, "generation_s": round(gen_s, 1), "kernels": kern}
+           "sweeps": sweeps, "table_slots": slots_pow2, "generation_s": round(gen_s, 1), "join_path": jp, "kernels": kern}
     eng.close()
     return out
 
