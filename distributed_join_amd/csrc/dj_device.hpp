@@ -194,9 +194,14 @@ struct Work {
     uint32_t publish_hints;       // 1: the link pass hands the previous batch's counters (the other bank) to the host
     uint32_t fused;               // 1: the link pass has copied every accepted event's message into its row already; the
                                   // resolve passes copy again where a later event of the batch wrote the same position
+    // bucketed join path (join_link_bucket_kernel / join_resolve_bucket_kernel)
+    uint64_t* bkeys;              // [BK_MAX_BUCKETS][RB_CAP] one key per linked event, in the bucket of its slot's range
+    unsigned int* bcursor;        // [BK_MAX_BUCKETS] keys per bucket; zero between batches (the second pass clears its own)
+    uint32_t bbuckets;            // buckets of this batch (a power of two)
+    uint32_t bshift;              // bucket of a slot = slot >> bshift
 };
 constexpr uint32_t SLOT_CREATED = 0x80000000u;      // tables have at most 2^30 slots
-enum { C_COMPLEX = 1, C_MAXCHAIN = 2, C_CXPOOL = 3, C_MID = 4, C_RECOPY = 5, C_COUNT = 8 };
+enum { C_COMPLEX = 1, C_MAXCHAIN = 2, C_CXPOOL = 3, C_MID = 4, C_RECOPY = 5, C_BOVF = 6, C_COUNT = 8 };    // C_BOVF: a bucket overflowed
 constexpr uint32_t CX_CAP = 65536;     // barriers with long chains per batch handled by the parallel path
 constexpr uint32_t CX_HASH = 262144;   // power of two, >= 2 * CX_CAP
 constexpr uint32_t CX_HOT_STRIDE = 8;  // pool entries per table line (64 bytes)

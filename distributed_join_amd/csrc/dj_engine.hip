@@ -60,6 +60,7 @@ struct dj_engine {
     std::recursive_mutex mu;     // entry points serialise themselves: callers may share an engine between threads
     Slot* slots_alt;             // second table for dj_compact (always all-empty between calls)
     uint64_t* q_alt;
+    int bucket_mode;             // -1: the bucketed join passes where they pay; 0: never; 1: wherever they apply (tests)
     int fuse_off;                // 1: the link pass never copies messages itself (dj_set_hot_path mode + 4: tests of the separate copy pass)
     int cx_force;                // -1: automatic; else bit 0: parallel hot-barrier kernels, bit 1: wide register replay (tests)
     unsigned int* h_maxchain;    // pinned: longest chain of the previous join batch (picks the hot-barrier kernels)
@@ -303,6 +304,10 @@ static int create_impl(dj_engine* e) {
     HIP_TRY(e, hipMemsetAsync(e->d_fork_contested, 0, 2 * 4, e->stream));
     ALLOC(e, e->d_counters, 2 * C_COUNT * 4);
     HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 2 * C_COUNT * 4, e->stream));
+    ALLOC(e, w.bkeys, (size_t)BK_MAX_BUCKETS * RB_CAP * 8);
+    ALLOC(e, w.bcursor, BK_MAX_BUCKETS * 4);
+    HIP_TRY(e, hipMemsetAsync(w.bcursor, 0, BK_MAX_BUCKETS * 4, e->stream));
+    w.bbuckets = w.bshift = 0;
     ALLOC(e, w.cx_keys, CX_HASH * 4);
     ALLOC(e, w.cx_val, CX_HASH * 4);
     ALLOC(e, w.cx_off, CX_CAP * 4);
@@ -361,6 +366,7 @@ extern "C" int dj_create(const dj_config* cfg, dj_engine** out) {
     e->compact_ev = nullptr;
     e->cx_force = -1;
     e->fuse_off = 0;
+    e->bucket_mode = -1;
     e->scratch_ptr = nullptr;
     for (int k = 0; k < DJ_PROF_KERNELS; ++k) { e->ev_start[k] = nullptr; e->ev_stop[k] = nullptr; e->ev_used[k] = 0; }
     int rc = create_impl(e);
@@ -390,11 +396,20 @@ extern "C" int dj_get_config(const dj_engine* e, dj_config* out) {
 }
 
 extern "C" int dj_set_hot_path(dj_engine* e, int mode) {
-    if (!e || mode < -1 || mode > 7) return DJ_E_INVALID;
+    if (!e || mode < -1 || mode > 23 || (mode >= 8 && mode < 16 && (mode & 7) == 7)) return DJ_E_INVALID;
     std::lock_guard<std::recursive_mutex> guard(e->mu);
+    if (mode < 0) {
+        e->bucket_mode = -1; e->fuse_off = 0; e->cx_force = -1;
+        return DJ_OK;
+    }
+    // + 8: the bucketed join passes never run; + 16: they run wherever they apply; both leave the other choices to the
+    // engine unless lower bits pin them as well (8 and 16 alone: everything else automatic)
+    e->bucket_mode = mode >= 16 ? 1 : mode >= 8 ? 0 : -1;
+    const bool only_bucket = mode == 8 || mode == 16;
+    mode &= 7;
     e->fuse_off = mode >= 4 ? 1 : 0;
     if (mode >= 4) mode -= 4;
-    e->cx_force = mode;
+    e->cx_force = only_bucket ? -1 : mode;
     return DJ_OK;
 }
 
@@ -583,6 +598,39 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
     // events per batch would have every one of them write its few rows) and not with messages in blocks of their own.
     w.fused = (!w.cx_on && e->t.max_message <= e->t.stride && e->fuse_off == 0) ? 1u : 0u;
     const uint32_t lanes = e->cfg.payload_stride / 16;
+    // h_maxchain[8] = barriers of the previous batch with 9..16 events: while there are thousands of them the
+    // register replay takes chains up to 16 (slower for everyone else, far cheaper than a wave per barrier)
+    const bool wide = e->cx_force >= 0 ? (e->cx_force & 2) != 0 : hint[8] >= WIDE_ON;
+    // Bucketed form of the link and resolve passes (no atomic per event): for batches that are large enough to fill
+    // the buckets' runs, small enough for a bucket to fit the second pass's LDS (1024 keys on average, 2048 at most),
+    // and whose previous batch showed no long chains (a hot barrier overflows its bucket: see join_relink_kernel).
+    const uint64_t slots = e->t.mask + 1;
+    bool bucket = !serial_only && w.fused && !wide && n <= (1u << 20) && e->bucket_mode != 0 &&
+                  (e->bucket_mode == 1 || (n >= 32768 && hint[0] < 2048 && hint[1] < 512));
+    if (bucket) {
+        uint32_t B = 16;
+        while (B < BK_MAX_BUCKETS && (uint64_t)B * 1024 < n) B <<= 1;
+        while (B > 1 && (uint64_t)B * 4 > slots) B >>= 1;
+        uint32_t shift = 0;
+        while ((slots >> shift) > B) ++shift;
+        w.bbuckets = B;
+        w.bshift = shift;
+        bucket = (uint64_t)B * 1024 >= n;        // (a tiny table cannot spread a large batch)
+    }
+    if (bucket) {
+        const uint32_t tiles = grid_for(n, BK_TILE);
+#define DJ_LINKB(G) join_link_bucket_kernel<G><<<tiles, BK_BLOCK, 0, e->stream>>>(e->t, w, d_recs, n, pitch, d_status, d_payloads)
+        if (lanes <= 4) LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINKB(4)));
+        else if (lanes <= 8) LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINKB(8)));
+        else if (lanes <= 16) LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINKB(16)));
+        else if (lanes <= 32) LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINKB(32)));
+        else LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINKB(64)));
+#undef DJ_LINKB
+        if (e->profiling) (void)hipEventRecord(e->ev_start[DJ_PROF_JOIN_RESOLVE], e->stream);
+        join_resolve_bucket_kernel<<<w.bbuckets, RB_T, 0, e->stream>>>(e->t, w, now_ms, d_status);
+        join_relink_kernel<<<512, 256, 0, e->stream>>>(e->t, w, n);
+        if (e->profiling) { (void)hipEventRecord(e->ev_stop[DJ_PROF_JOIN_RESOLVE], e->stream); e->ev_used[DJ_PROF_JOIN_RESOLVE] = 1; }
+    } else {
 #define DJ_LINK(HOT, G, BLOCK) join_link_kernel<HOT, G><<<grid_for(n, BLOCK), BLOCK, 0, e->stream>>>(e->t, w, d_recs, n, pitch, d_status, d_payloads)
     if (w.cx_on) LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINK(true, 0, LINK_BLOCK_HOT)));
     else if (!w.fused) LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINK(false, 0, LINK_BLOCK)));
@@ -592,13 +640,11 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
     else if (lanes <= 32) LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINK(false, 32, LINK_BLOCK)));
     else LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINK(false, 64, LINK_BLOCK)));
 #undef DJ_LINK
-    // h_maxchain[8] = barriers of the previous batch with 9..16 events: while there are thousands of them the
-    // register replay takes chains up to 16 (slower for everyone else, far cheaper than a wave per barrier)
-    const bool wide = e->cx_force >= 0 ? (e->cx_force & 2) != 0 : hint[8] >= WIDE_ON;
     if (wide)
         LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_kernel<CHAIN_REG_WIDE><<<grid_for(n, RESOLVE_BLOCK), RESOLVE_BLOCK, 0, e->stream>>>(e->t, w, (uint32_t)n, now_ms, d_status)));
     else
         LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_kernel<CHAIN_REG><<<grid_for(n, RESOLVE_BLOCK), RESOLVE_BLOCK, 0, e->stream>>>(e->t, w, (uint32_t)n, now_ms, d_status)));
+    }
     // Long chains (hot barriers): the previous batch's longest chain, read back without waiting, picks
     // between the serial kernel and the parallel cx_* kernels.  Both give the same results.
     // One wave per long chain; the grid follows the previous batch's number of them (an empty pass of 4096

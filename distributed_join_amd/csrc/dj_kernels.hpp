@@ -379,47 +379,18 @@ __device__ inline int32_t replay_one(const Table& t, uint64_t s, uint32_t slab, 
 constexpr int CHAIN_REG = 8, CHAIN_REG_WIDE = 16;
 constexpr int RESOLVE_BLOCK = 512;
 
+// The register replay of one barrier's m <= CR events of this batch (idx[k] their array indices, nd[k] their link
+// words: position and max-wait; unused entries carry index 0xFFFFFFFF), in array order, with plain loads and stores by
+// the one thread that owns the barrier for this batch.  Returns whether the barrier completed.
 template <int CR>
-__global__ void __launch_bounds__(RESOLVE_BLOCK) __attribute__((amdgpu_waves_per_eu(CR <= 8 ? 8 : 4)))
-join_resolve_kernel(Table t, Work w, uint32_t n, uint64_t now, int32_t* status) {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    // block pops of the copy pass stop at the tails as they are now (nothing touches these rings here)
-    if (blockIdx.x == 0 && threadIdx.x < OVF_CLASSES) t.oring_tail_snap[threadIdx.x] = t.oring_tail[threadIdx.x];
-    bool is_complex = false, mid = false, completed = false;
-    uint32_t s = tid < n ? w.ev_slot[tid] : 0xFFFFFFFFu;
-    // The event that linked FIRST (it found the chain empty) resolves the barrier: it knows that from
-    // its own link word, so every other event leaves without touching the table again.
-    const uint64_t own = s != 0xFFFFFFFFu ? w.node[tid] : 0;
-    if (s != 0xFFFFFFFFu && node_next(own) != 0) s = 0xFFFFFFFFu;
-    uint4 info = make_uint4(0, 0, 0, 0);
-    uint64_t bits0 = 0;
-    if (s != 0xFFFFFFFFu) {
-        info = reinterpret_cast<const uint4*>(&t.slots[s])[1];   // count, meta, slab, chain
-        bits0 = t.slots[s].bits;                                 // requested with it: one round trip
-    }
-    if (s != 0xFFFFFFFFu) {
-        Slot* sl = &t.slots[s];
-        const uint32_t count = info.x, slab = info.z;
-        uint32_t cur = info.w;
-        // walk the chain (newest link first)
-        uint32_t idx[CR];
-        uint64_t nd[CR];
-        int m = 0;
-#pragma unroll
-        for (int k = 0; k < CR; ++k) {
-            idx[k] = 0xFFFFFFFFu;
-            nd[k] = 0;
-            if (cur != 0) {
-                idx[k] = cur - 1;
-                nd[k] = cur - 1 == tid ? own : w.node[cur - 1];      // every chain ends at this thread's own event
-                cur = node_next(nd[k]);
-                ++m;
-            }
-        }
-        if (cur != 0 || (info.y & META_KX_MASK)) {
-            is_complex = true;      // a long chain, or a barrier whose count went back (only the wave kernel replays those)
-        } else {
-            mid = m > CHAIN_REG;
+__device__ __forceinline__ bool replay_short_chain(const Table& t, const Work& w, uint32_t s, const uint4& info, uint64_t bits0,
+                                          const uint32_t (&idx)[CR], const uint64_t (&nd)[CR], int m, uint64_t now,
+                                          int32_t* status) {
+    Slot* sl = &t.slots[s];
+    const uint32_t count = info.x, slab = info.z;
+    bool completed = false;
+    {
+        {
             ReplayState r;
             r.count = count;
             r.bits = count > 64 ? 0 : bits0;
@@ -464,12 +435,281 @@ join_resolve_kernel(Table t, Work w, uint32_t n, uint64_t now, int32_t* status) 
             else if (r.pa_dirty) { t.q[s] = r.pa; note_queue_date(t, s, r.pa); }   // ZADD both at the nearer date, redis.clj:270-271
         }
     }
+    return completed;
+}
+
+template <int CR>
+__global__ void __launch_bounds__(RESOLVE_BLOCK) __attribute__((amdgpu_waves_per_eu(CR <= 8 ? 8 : 4)))
+join_resolve_kernel(Table t, Work w, uint32_t n, uint64_t now, int32_t* status) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    // block pops of the copy pass stop at the tails as they are now (nothing touches these rings here)
+    if (blockIdx.x == 0 && threadIdx.x < OVF_CLASSES) t.oring_tail_snap[threadIdx.x] = t.oring_tail[threadIdx.x];
+    bool is_complex = false, mid = false, completed = false;
+    uint32_t s = tid < n ? w.ev_slot[tid] : 0xFFFFFFFFu;
+    // The event that linked FIRST (it found the chain empty) resolves the barrier: it knows that from
+    // its own link word, so every other event leaves without touching the table again.
+    const uint64_t own = s != 0xFFFFFFFFu ? w.node[tid] : 0;
+    if (s != 0xFFFFFFFFu && node_next(own) != 0) s = 0xFFFFFFFFu;
+    uint4 info = make_uint4(0, 0, 0, 0);
+    uint64_t bits0 = 0;
+    if (s != 0xFFFFFFFFu) {
+        info = reinterpret_cast<const uint4*>(&t.slots[s])[1];   // count, meta, slab, chain
+        bits0 = t.slots[s].bits;                                 // requested with it: one round trip
+    }
+    if (s != 0xFFFFFFFFu) {
+        Slot* sl = &t.slots[s];
+        const uint32_t count = info.x, slab = info.z;
+        uint32_t cur = info.w;
+        // walk the chain (newest link first)
+        uint32_t idx[CR];
+        uint64_t nd[CR];
+        int m = 0;
+#pragma unroll
+        for (int k = 0; k < CR; ++k) {
+            idx[k] = 0xFFFFFFFFu;
+            nd[k] = 0;
+            if (cur != 0) {
+                idx[k] = cur - 1;
+                nd[k] = cur - 1 == tid ? own : w.node[cur - 1];      // every chain ends at this thread's own event
+                cur = node_next(nd[k]);
+                ++m;
+            }
+        }
+        if (cur != 0 || (info.y & META_KX_MASK)) {
+            is_complex = true;      // a long chain, or a barrier whose count went back (only the wave kernel replays those)
+        } else {
+            mid = m > CHAIN_REG;
+            completed = replay_short_chain<CR>(t, w, s, info, bits0, idx, nd, m, now, status);
+        }
+    }
     ready_append_wave(t, completed, s, tid >> 6);
     uint32_t at = wave_append(&w.counters[C_COMPLEX], is_complex);
     if (is_complex) w.complex_[at] = s;
     if (CR > CHAIN_REG && ((tid >> 6) & 7) == 0) {      // one wave in eight reports how many such chains it replayed
         const uint32_t k = (uint32_t)__popcll(__ballot(mid));
         if ((threadIdx.x & 63) == 0 && k) atomicAdd(&w.counters[C_MID], 8 * k);
+    }
+}
+
+// =====================================================================================
+// Bucketed form of the two join passes (same results as join_link_kernel<false, G> + join_resolve_kernel<8>).
+//
+// The atomic exchange per event is what the chain form pays most for (about 35 us per 2^20 events wherever the word
+// lives).  Here the first pass does everything else the link pass does, in the same order (records and messages in
+// array order, probe, answers, message into its row), and instead of linking the event on its slot it files an 8-byte
+// key {slot, event, position} under the bucket of the slot's range: a block takes a tile of 4096 events, counts its
+// keys per bucket in LDS, reserves their places with ONE atomic per bucket and tile, and writes them out of LDS in
+// runs.  The second pass has one block per bucket: it chains its keys per slot in LDS (hash + exchange, both in LDS),
+// and the first key of every slot replays that barrier's events from LDS with the code of the register replay, so a
+// touched barrier's slot is read and written once and no link word is ever chased through memory.
+// Barriers the register replay does not take (more than CHAIN_REG events, or a count that went back) get their chain
+// written to the slot and the link words after all and go on the list of the long-chain pass, as in the chain form.
+// A bucket that would overflow its LDS (one range with more than RB_CAP events: a hot barrier nobody has flagged yet)
+// raises C_BOVF: the second pass then does nothing, join_relink_kernel links every event the old way and puts every
+// touched barrier on the long-chain pass's list (slow, correct, and the host leaves the bucketed form from the next
+// batch on, whose hints show the long chain).
+// =====================================================================================
+constexpr int BK_TILE = 4096, BK_BLOCK = 1024, BK_MAX_BUCKETS = 1024;
+constexpr int RB_T = 512, RB_EPT = 4, RB_CAP = RB_T * RB_EPT, RB_H = RB_CAP;    // (as many cells as keys at most: a free cell is always left for a new slot)
+// key: slot inside its bucket's range << 35 | event index (24 bits) << 11 | has-max-wait << 10 | position (10 bits)
+__device__ inline uint64_t bkey_pack(uint32_t slot_local, uint32_t i, uint32_t pos, bool has_mw) {
+    return ((uint64_t)slot_local << 35) | ((uint64_t)i << 11) | (has_mw ? 1024u : 0u) | pos;
+}
+__device__ inline uint32_t bkey_event(uint64_t k) { return (uint32_t)(k >> 11) & 0xFFFFFFu; }
+
+template <int G>
+__global__ void __launch_bounds__(BK_BLOCK) __attribute__((amdgpu_waves_per_eu(8)))
+join_link_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t pitch, int32_t* status, const uint8_t* payloads) {
+    __shared__ uint32_t hist[BK_MAX_BUCKETS], off[BK_MAX_BUCKETS], base[BK_MAX_BUCKETS];
+    __shared__ uint64_t stage[BK_TILE];
+    __shared__ uint16_t stage_b[BK_TILE];
+    __shared__ uint32_t wsum[BK_BLOCK / 64];
+    const uint32_t tix = threadIdx.x, lane = tix & 63, wave = tix >> 6;
+    const uint32_t B = w.bbuckets, shift = w.bshift;
+    for (uint32_t b = tix; b < B; b += BK_BLOCK) hist[b] = 0;
+    // the previous batch's counters (the bank this batch does not use) are final: to the host's memory, then to zero
+    if (blockIdx.x == 0 && tix < C_COUNT) {
+        if (w.publish_hints) {
+            if (tix == C_COMPLEX) w.hint[0] = w.counters_next[C_COMPLEX];
+            if (tix == C_MAXCHAIN) w.hint[1] = w.counters_next[C_MAXCHAIN];
+            if (tix == C_MID) w.hint[8] = w.counters_next[C_MID];
+        }
+        w.counters_next[tix] = 0;
+    }
+    __syncthreads();
+    uint64_t key[4];
+    uint32_t bk[4], rank[4];
+    bool linked[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t i = blockIdx.x * BK_TILE + wave * 256 + k * 64 + lane;
+        uint64_t row_off = ~0ull;
+        uint32_t row_len = 0;
+        bool stores_meta = false;
+        key[k] = 0; bk[k] = 0; rank[k] = 0; linked[k] = false;
+        if (i < n) {
+            const ulonglong2 a = reinterpret_cast<const ulonglong2*>(recs)[2 * (size_t)i];
+            const uint4 b = reinterpret_cast<const uint4*>(recs)[2 * (size_t)i + 1];  // position, len, max_wait, -
+            int32_t st = 0;
+            int64_t s = -1;
+            uint4 info = make_uint4(0, 0, 0, 0);
+            if (b.y > t.max_message || b.y > pitch) {
+                st = DJ_JOIN_TOO_LONG;                         // store.clj:24-26
+            } else if (b.z >= NODE_MW_LIMIT) {
+                st = DJ_JOIN_BAD_MAX_WAIT;
+            } else {
+                s = find_slot(t, a.x, a.y, &info);
+                if (s < 0 || !(info.y & META_HAS) || info.z == 0) st = DJ_JOIN_NOT_FOUND;   // redis.clj:152
+                else if (b.x >= info.x) st = DJ_JOIN_BAD_POSITION;                          // redis.clj:153
+            }
+            if (st != 0) {
+                status[i] = st;
+                w.ev_slot[i] = 0xFFFFFFFFu;
+            } else {
+                status[i] = DJ_JOIN_WAITING;
+                const bool pm = (info.y & META_PMD) || b.y != t.stride || b.z != 0;
+                stores_meta = pm;
+                const uint32_t kc = slab_class(info.x, info.y);
+                if (pm && !(info.y & META_PMD)) atomicOr(&t.slots[s].meta, META_PMD);
+                row_off = (uint64_t)info.z * 64 + slab_payload_off(kc) + (uint64_t)b.x * t.stride;
+                row_len = b.y;
+                if (pm) slab_posmeta(t, info.z, kc)[b.x] = make_uint2(b.y, b.z);
+                const uint32_t slot = (uint32_t)s;
+                w.ev_slot[i] = slot;
+                w.node[i] = node_pack(0, b.x, b.z);       // position and max-wait, for the long-chain pass
+                key[k] = bkey_pack(slot & ((1u << shift) - 1), i, b.x, b.z != 0);
+                bk[k] = slot >> shift;
+                linked[k] = true;
+                rank[k] = atomicAdd(&hist[bk[k]], 1u);
+            }
+        }
+        wave_copy_rows<G>(t, payloads, pitch, (uint64_t)i - lane, row_off, row_len);
+        // a sample for the host: how ragged is the traffic (the batch's first 4 x 64 events)
+        if (blockIdx.x == 0 && wave == 0) {
+            const uint64_t m = __ballot(stores_meta);
+            if (lane == 0) w.hint[4 + k] = (unsigned int)__popcll(m);
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the bucket counts (one per thread), one cursor atomic per bucket that has keys
+    {
+        const uint32_t c = tix < B ? hist[tix] : 0;
+        const uint32_t incl = wave_incl_scan(c);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t bw = 0;
+        for (uint32_t v = 0; v < wave; ++v) bw += wsum[v];
+        if (tix < B) {
+            off[tix] = bw + incl - c;
+            base[tix] = c ? a_add(&w.bcursor[tix], c) : 0u;
+            if (c && base[tix] + c > (uint32_t)RB_CAP) a_store(&w.counters[C_BOVF], 1u);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (linked[k]) {
+            stage[off[bk[k]] + rank[k]] = key[k];
+            stage_b[off[bk[k]] + rank[k]] = (uint16_t)bk[k];
+        }
+    __syncthreads();
+    // the keys leave LDS in bucket order: neighbouring threads write neighbouring keys of one bucket
+    const uint32_t total = off[B - 1] + hist[B - 1];
+    for (uint32_t e = tix; e < total; e += BK_BLOCK) {
+        const uint32_t bq = stage_b[e];
+        const uint32_t at = base[bq] + (e - off[bq]);
+        if (at < (uint32_t)RB_CAP) w.bkeys[(size_t)bq * RB_CAP + at] = stage[e];
+    }
+}
+
+__global__ void __launch_bounds__(RB_T) __attribute__((amdgpu_waves_per_eu(8)))
+join_resolve_bucket_kernel(Table t, Work w, uint64_t now, int32_t* status) {
+    __shared__ uint32_t hkey[RB_H];        // slot inside the range + 1, 0 = free
+    __shared__ uint32_t hhead[RB_H];       // newest key of the slot + 1
+    __shared__ uint16_t nxt[RB_CAP];       // the key filed before it on the same slot + 1, 0 = none: the slot's first key
+    __shared__ uint16_t cellof[RB_CAP];
+    __shared__ uint64_t kbuf[RB_CAP];
+    const uint32_t tix = threadIdx.x, b = blockIdx.x;
+    uint32_t nb = w.bcursor[b];
+    __syncthreads();
+    if (tix == 0) w.bcursor[b] = 0;        // for the next batch
+    if (a_load(&w.counters[C_BOVF]) != 0 || nb == 0) return;       // the same in every thread
+    if (nb > (uint32_t)RB_CAP) nb = RB_CAP;                         // (cannot be: C_BOVF would be set)
+    for (uint32_t c = tix; c < (uint32_t)RB_H; c += RB_T) { hkey[c] = 0; hhead[c] = 0; }
+    for (uint32_t e = tix; e < nb; e += RB_T) kbuf[e] = w.bkeys[(size_t)b * RB_CAP + e];
+    __syncthreads();
+    for (uint32_t e = tix; e < nb; e += RB_T) {
+        const uint32_t sl = (uint32_t)(kbuf[e] >> 35);
+        uint32_t c = ((sl * 2654435761u) >> 19) & (RB_H - 1);
+        for (;; c = (c + 1) & (RB_H - 1)) {
+            const uint32_t old = atomicCAS(&hkey[c], 0u, sl + 1);
+            if (old == 0 || old == sl + 1) break;
+        }
+        cellof[e] = (uint16_t)c;
+        nxt[e] = (uint16_t)atomicExch(&hhead[c], e + 1);
+    }
+    __syncthreads();
+    for (uint32_t e0 = 0; e0 < nb; e0 += RB_T) {          // uniform: the list appends below are wave-cooperative
+        const uint32_t e = e0 + tix;
+        const bool first = e < nb && nxt[e] == 0;
+        bool is_complex = false, completed = false;
+        uint32_t s = 0xFFFFFFFFu;
+        if (first) {
+            const uint32_t c = cellof[e];
+            s = (b << w.bshift) | (hkey[c] - 1);
+            const uint4 info = reinterpret_cast<const uint4*>(&t.slots[s])[1];   // count, meta, slab, chain
+            const uint64_t bits0 = t.slots[s].bits;
+            uint32_t cur = hhead[c];
+            uint32_t idx[CHAIN_REG];
+            uint64_t nd[CHAIN_REG];
+            int m = 0;
+#pragma unroll
+            for (int k = 0; k < CHAIN_REG; ++k) {
+                idx[k] = 0xFFFFFFFFu;
+                nd[k] = 0;
+                if (cur != 0) {
+                    const uint64_t kv = kbuf[cur - 1];
+                    idx[k] = bkey_event(kv);
+                    nd[k] = (kv & 1024u) ? w.node[idx[k]] : node_pack(0, (uint32_t)kv & 1023u, 0);
+                    cur = nxt[cur - 1];
+                    ++m;
+                }
+            }
+            if (cur != 0 || (info.y & META_KX_MASK)) {
+                // not for the register replay: the chain goes where the long-chain pass looks for it
+                is_complex = true;
+                uint32_t c2 = hhead[c];
+                t.slots[s].chain = bkey_event(kbuf[c2 - 1]) + 1;
+                while (c2 != 0) {
+                    const uint32_t i = bkey_event(kbuf[c2 - 1]), nx = nxt[c2 - 1];
+                    if (nx != 0) w.node[i] |= (uint64_t)(bkey_event(kbuf[nx - 1]) + 1);
+                    c2 = nx;
+                }
+            } else {
+                completed = replay_short_chain<CHAIN_REG>(t, w, s, info, bits0, idx, nd, m, now, status);
+            }
+        }
+        ready_append_wave(t, completed, s, b * (RB_T / 64) + (tix >> 6) + (e0 / RB_T));
+        const uint32_t at = wave_append(&w.counters[C_COMPLEX], is_complex);
+        if (is_complex) w.complex_[at] = s;
+    }
+}
+
+// After a bucket overflow: every linked event enters its barrier's chain the way join_link_kernel does it, and every
+// touched barrier goes on the long-chain pass's list.  Leaves at once otherwise.
+__global__ void __launch_bounds__(256) join_relink_kernel(Table t, Work w, uint32_t n) {
+    if (a_load(&w.counters[C_BOVF]) == 0) return;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * 256; i0 < n; i0 += (uint64_t)gridDim.x * 256) {
+        const uint64_t i = i0 + threadIdx.x;
+        const uint32_t s = i < n ? w.ev_slot[i] : 0xFFFFFFFFu;
+        bool first = false;
+        if (s != 0xFFFFFFFFu) {
+            const uint32_t prev = a_xchg(&t.slots[s].chain, (uint32_t)i + 1);
+            w.node[i] |= (uint64_t)prev;
+            first = prev == 0;
+        }
+        const uint32_t at = wave_append(&w.counters[C_COMPLEX], first);
+        if (first) w.complex_[at] = s;
     }
 }
 

@@ -111,7 +111,7 @@ def run_oplog(d, rng, n_barriers, counts, stride, rounds, batch, hot=None, var_l
     d.check_all_snapshots()
 
 
-@pytest.mark.parametrize("hot_mode", [-1, 1, 2, 3, 4, 6])
+@pytest.mark.parametrize("hot_mode", [-1, 1, 2, 3, 4, 6, 8, 16])
 def test_small_counts_many_duplicates(oracle_lib, hot_mode):
     rng = np.random.default_rng(1)
     nb = 40
@@ -124,7 +124,7 @@ def test_small_counts_many_duplicates(oracle_lib, hot_mode):
         e.close()
 
 
-@pytest.mark.parametrize("hot_mode", [-1, 0, 2, 4])
+@pytest.mark.parametrize("hot_mode", [-1, 0, 2, 4, 16])
 def test_thousands_of_barriers_with_ten_events_a_batch(oracle_lib, hot_mode):
     """About ten events per barrier and batch on thousands of barriers: chains of 9..16 events, which the
     engine (left to itself) moves from the long-chain kernels to the 16-event register replay after the first
@@ -140,7 +140,7 @@ def test_thousands_of_barriers_with_ten_events_a_batch(oracle_lib, hot_mode):
         e.close()
 
 
-@pytest.mark.parametrize("hot_mode", [-1, 0, 1, 4])
+@pytest.mark.parametrize("hot_mode", [-1, 0, 1, 4, 16])
 def test_hot_barrier_long_chains(oracle_lib, hot_mode):
     rng = np.random.default_rng(2)
     nb = 30
@@ -154,7 +154,7 @@ def test_hot_barrier_long_chains(oracle_lib, hot_mode):
         e.close()
 
 
-@pytest.mark.parametrize("hot_mode", [-1, 0])
+@pytest.mark.parametrize("hot_mode", [-1, 0, 16])
 def test_chain_longer_than_one_lane_walks(oracle_lib, hot_mode):
     """A third of a 30 000-event batch on one barrier that nobody knew to be hot: the serial long-chain
     kernel gives the walk up after 256 links (batch size / 512, at least 256) and scans the batch instead (every batch with the serial
@@ -171,7 +171,7 @@ def test_chain_longer_than_one_lane_walks(oracle_lib, hot_mode):
         e.close()
 
 
-@pytest.mark.parametrize("hot_mode", [-1, 1])
+@pytest.mark.parametrize("hot_mode", [-1, 1, 16])
 def test_many_hot_barriers_at_once(oracle_lib, hot_mode):
     """Every barrier receives hundreds of events per batch, so all of them get flagged hot: more hot barriers
     than one block of the link pass keeps lists for (64), which exercises the block-local lists, their
@@ -187,7 +187,7 @@ def test_many_hot_barriers_at_once(oracle_lib, hot_mode):
         e.close()
 
 
-@pytest.mark.parametrize("lo,hi,hot_mode", [(1, 12, -1), (1, 12, 4), (5, 8, -1), (40, 90, -1), (2, 300, -1), (2, 300, 1), (55, 70, 4)])
+@pytest.mark.parametrize("lo,hi,hot_mode", [(1, 12, -1), (1, 12, 4), (5, 8, -1), (40, 90, -1), (2, 300, -1), (2, 300, 1), (55, 70, 4), (1, 12, 16), (40, 90, 16), (2, 300, 16)])
 def test_failed_publish_writes_an_older_count_back(oracle_lib, lo, hi, hot_mode):
     """Barriers are re-forked with another count while continuations of their earlier lives are in flight, and every
     second publish fails: the write-back sets a count below or above the one the stored messages arrived under
@@ -202,7 +202,7 @@ def test_failed_publish_writes_an_older_count_back(oracle_lib, lo, hi, hot_mode)
     e.close()
 
 
-@pytest.mark.parametrize("hot_mode", [-1, 0, 4])
+@pytest.mark.parametrize("hot_mode", [-1, 0, 4, 16])
 def test_count_written_back_below_stored_messages_same_slab_size(oracle_lib, hot_mode):
     """core.clj:107-111 step by step.  A barrier forked with count 5 times out and its publish is in flight; it is
     forked again with count 8 and gets positions 5 and 6; the publish fails and writes count 5 back (same slab size:
@@ -240,7 +240,7 @@ def test_count_written_back_below_stored_messages_same_slab_size(oracle_lib, hot
     e.close()
 
 
-@pytest.mark.parametrize("hot_mode", [-1, 0, 1, 4])
+@pytest.mark.parametrize("hot_mode", [-1, 0, 1, 4, 16])
 def test_large_counts_multiword_bitmaps(oracle_lib, hot_mode):
     rng = np.random.default_rng(3)
     nb = 12

@@ -43,6 +43,16 @@ def main():
          dict(recount=(2, 300), fail_every=2, hot=5), dict()),
         ("the same with long messages", 800 * scale, (1, 91), 64, 12, 8000 * scale,
          dict(long_to=4096, recount=(1, 90), fail_every=2), dict(max_message=4096)),
+        # the bucketed join passes pinned (by themselves they start at 32768 events per batch)
+        ("small counts, bucketed passes", 4000 * scale, (1, 9), 64, 20, 30000 * scale, dict(unknown=50), dict(hot_mode=16)),
+        ("hot barrier, bucketed passes", 2000 * scale, (2, 65), 64, 15, 40000 * scale, dict(hot=7), dict(hot_mode=16)),
+        ("ten events per barrier and batch, bucketed passes", 6000, (2, 17), 64, 6, 60000 * scale, dict(), dict(hot_mode=16)),
+        ("large counts, bucketed passes", 300 * scale, (60, 1000), 64, 10, 60000 * scale, dict(hot=11), dict(hot_mode=16)),
+        ("variable lengths, bucketed passes", 3000 * scale, (1, 20), 256, 12, 20000 * scale, dict(var_len=True), dict(hot_mode=16)),
+        ("re-forks to other counts, every second publish fails, bucketed passes", 1500 * scale, (1, 13), 64, 25, 12000 * scale,
+         dict(recount=(1, 12), fail_every=2), dict(hot_mode=16)),
+        ("counts 2..300 with re-forks and a hot barrier, bucketed passes", 400 * scale, (2, 301), 64, 16, 30000 * scale,
+         dict(recount=(2, 300), fail_every=2, hot=5), dict(hot_mode=16)),
     ]
     for seed in range(seeds):
         for name, nb, (lo, hi), stride, rounds, batch, kw, ekw in cases:
@@ -56,7 +66,7 @@ def main():
                 run_oplog(d, rng, nb, counts, stride, rounds=rounds, batch=batch, **kw)
             finally:
                 e.close()
-            print(f"seed {seed} {name:32s} ok  {time.time() - t0:6.1f} s", flush=True)
+            print(f"seed {seed} {name:40s} ok  {time.time() - t0:6.1f} s", flush=True)
     print("soak ok")
 
 
