@@ -603,7 +603,7 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
     const bool wide = e->cx_force >= 0 ? (e->cx_force & 2) != 0 : hint[8] >= WIDE_ON;
     // Bucketed form of the link and resolve passes (no atomic per event): for batches that are large enough to fill
     // the buckets' runs, small enough for a bucket to fit the second pass's LDS (1024 keys on average, 2048 at most),
-    // and whose previous batch showed no long chains (a hot barrier overflows its bucket: see join_relink_kernel).
+    // and whose previous batch showed no long chains (a hot barrier overflows its bucket, and the batch then falls back to chains).
     const uint64_t slots = e->t.mask + 1;
     bool bucket = !serial_only && w.fused && !wide && n <= (1u << 20) && e->bucket_mode != 0 &&
                   (e->bucket_mode == 1 || (n >= 32768 && hint[0] < 2048 && hint[1] < 512));
@@ -626,10 +626,7 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
         else if (lanes <= 32) LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINKB(32)));
         else LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINKB(64)));
 #undef DJ_LINKB
-        if (e->profiling) (void)hipEventRecord(e->ev_start[DJ_PROF_JOIN_RESOLVE], e->stream);
-        join_resolve_bucket_kernel<<<w.bbuckets, RB_T, 0, e->stream>>>(e->t, w, now_ms, d_status);
-        join_relink_kernel<<<512, 256, 0, e->stream>>>(e->t, w, n);
-        if (e->profiling) { (void)hipEventRecord(e->ev_stop[DJ_PROF_JOIN_RESOLVE], e->stream); e->ev_used[DJ_PROF_JOIN_RESOLVE] = 1; }
+        LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_bucket_kernel<<<w.bbuckets, RB_T, 0, e->stream>>>(e->t, w, d_recs, n, now_ms, d_status)));
     } else {
 #define DJ_LINK(HOT, G, BLOCK) join_link_kernel<HOT, G><<<grid_for(n, BLOCK), BLOCK, 0, e->stream>>>(e->t, w, d_recs, n, pitch, d_status, d_payloads)
     if (w.cx_on) LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINK(true, 0, LINK_BLOCK_HOT)));

@@ -505,9 +505,9 @@ join_resolve_kernel(Table t, Work w, uint32_t n, uint64_t now, int32_t* status) 
 // Barriers the register replay does not take (more than CHAIN_REG events, or a count that went back) get their chain
 // written to the slot and the link words after all and go on the list of the long-chain pass, as in the chain form.
 // A bucket that would overflow its LDS (one range with more than RB_CAP events: a hot barrier nobody has flagged yet)
-// raises C_BOVF: the second pass then does nothing, join_relink_kernel links every event the old way and puts every
-// touched barrier on the long-chain pass's list (slow, correct, and the host leaves the bucketed form from the next
-// batch on, whose hints show the long chain).
+// raises C_BOVF: the second pass then links every event the old way instead and puts every touched barrier on the
+// long-chain pass's list (slow, correct, and the host leaves the bucketed form from the next batch on, whose hints
+// show the long chain).
 // =====================================================================================
 constexpr int BK_TILE = 4096, BK_BLOCK = 1024, BK_MAX_BUCKETS = 1024;
 constexpr int RB_T = 512, RB_EPT = 4, RB_CAP = RB_T * RB_EPT, RB_H = RB_CAP;    // (as many cells as keys at most: a free cell is always left for a new slot)
@@ -576,7 +576,6 @@ join_link_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, ui
                 if (pm) slab_posmeta(t, info.z, kc)[b.x] = make_uint2(b.y, b.z);
                 const uint32_t slot = (uint32_t)s;
                 w.ev_slot[i] = slot;
-                w.node[i] = node_pack(0, b.x, b.z);       // position and max-wait, for the long-chain pass
                 key[k] = bkey_pack(slot & ((1u << shift) - 1), i, b.x, b.z != 0);
                 bk[k] = slot >> shift;
                 linked[k] = true;
@@ -623,7 +622,7 @@ join_link_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, ui
 }
 
 __global__ void __launch_bounds__(RB_T) __attribute__((amdgpu_waves_per_eu(8)))
-join_resolve_bucket_kernel(Table t, Work w, uint64_t now, int32_t* status) {
+join_resolve_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t now, int32_t* status) {
     __shared__ uint32_t hkey[RB_H];        // slot inside the range + 1, 0 = free
     __shared__ uint32_t hhead[RB_H];       // newest key of the slot + 1
     __shared__ uint16_t nxt[RB_CAP];       // the key filed before it on the same slot + 1, 0 = none: the slot's first key
@@ -633,7 +632,25 @@ join_resolve_bucket_kernel(Table t, Work w, uint64_t now, int32_t* status) {
     uint32_t nb = w.bcursor[b];
     __syncthreads();
     if (tix == 0) w.bcursor[b] = 0;        // for the next batch
-    if (a_load(&w.counters[C_BOVF]) != 0 || nb == 0) return;       // the same in every thread
+    if (a_load(&w.counters[C_BOVF]) != 0) {
+        // A bucket overflowed (the same answer in every thread of every block): every linked event enters its barrier's
+        // chain the way join_link_kernel does it, and every touched barrier goes on the long-chain pass's list.
+        for (uint64_t i0 = (uint64_t)b * RB_T; i0 < n; i0 += (uint64_t)gridDim.x * RB_T) {
+            const uint64_t i = i0 + tix;
+            const uint32_t s = i < n ? w.ev_slot[i] : 0xFFFFFFFFu;
+            bool first = false;
+            if (s != 0xFFFFFFFFu) {
+                const uint4 rb = reinterpret_cast<const uint4*>(recs)[2 * (size_t)i + 1];      // position, len, max_wait, -
+                const uint32_t prev = a_xchg(&t.slots[s].chain, (uint32_t)i + 1);
+                w.node[i] = node_pack(prev, rb.x, rb.z);
+                first = prev == 0;
+            }
+            const uint32_t at = wave_append(&w.counters[C_COMPLEX], first);
+            if (first) w.complex_[at] = s;
+        }
+        return;
+    }
+    if (nb == 0) return;                   // the same in every thread
     if (nb > (uint32_t)RB_CAP) nb = RB_CAP;                         // (cannot be: C_BOVF would be set)
     for (uint32_t c = tix; c < (uint32_t)RB_H; c += RB_T) { hkey[c] = 0; hhead[c] = 0; }
     for (uint32_t e = tix; e < nb; e += RB_T) kbuf[e] = w.bkeys[(size_t)b * RB_CAP + e];
@@ -670,7 +687,7 @@ join_resolve_bucket_kernel(Table t, Work w, uint64_t now, int32_t* status) {
                 if (cur != 0) {
                     const uint64_t kv = kbuf[cur - 1];
                     idx[k] = bkey_event(kv);
-                    nd[k] = (kv & 1024u) ? w.node[idx[k]] : node_pack(0, (uint32_t)kv & 1023u, 0);
+                    nd[k] = node_pack(0, (uint32_t)kv & 1023u, (kv & 1024u) ? recs[idx[k]].max_wait_s : 0u);
                     cur = nxt[cur - 1];
                     ++m;
                 }
@@ -681,8 +698,10 @@ join_resolve_bucket_kernel(Table t, Work w, uint64_t now, int32_t* status) {
                 uint32_t c2 = hhead[c];
                 t.slots[s].chain = bkey_event(kbuf[c2 - 1]) + 1;
                 while (c2 != 0) {
-                    const uint32_t i = bkey_event(kbuf[c2 - 1]), nx = nxt[c2 - 1];
-                    if (nx != 0) w.node[i] |= (uint64_t)(bkey_event(kbuf[nx - 1]) + 1);
+                    const uint64_t kv = kbuf[c2 - 1];
+                    const uint32_t i = bkey_event(kv), nx = nxt[c2 - 1];
+                    w.node[i] = node_pack(nx != 0 ? bkey_event(kbuf[nx - 1]) + 1 : 0u, (uint32_t)kv & 1023u,
+                                          (kv & 1024u) ? recs[i].max_wait_s : 0u);
                     c2 = nx;
                 }
             } else {
@@ -692,24 +711,6 @@ join_resolve_bucket_kernel(Table t, Work w, uint64_t now, int32_t* status) {
         ready_append_wave(t, completed, s, b * (RB_T / 64) + (tix >> 6) + (e0 / RB_T));
         const uint32_t at = wave_append(&w.counters[C_COMPLEX], is_complex);
         if (is_complex) w.complex_[at] = s;
-    }
-}
-
-// After a bucket overflow: every linked event enters its barrier's chain the way join_link_kernel does it, and every
-// touched barrier goes on the long-chain pass's list.  Leaves at once otherwise.
-__global__ void __launch_bounds__(256) join_relink_kernel(Table t, Work w, uint32_t n) {
-    if (a_load(&w.counters[C_BOVF]) == 0) return;
-    for (uint64_t i0 = (uint64_t)blockIdx.x * 256; i0 < n; i0 += (uint64_t)gridDim.x * 256) {
-        const uint64_t i = i0 + threadIdx.x;
-        const uint32_t s = i < n ? w.ev_slot[i] : 0xFFFFFFFFu;
-        bool first = false;
-        if (s != 0xFFFFFFFFu) {
-            const uint32_t prev = a_xchg(&t.slots[s].chain, (uint32_t)i + 1);
-            w.node[i] |= (uint64_t)prev;
-            first = prev == 0;
-        }
-        const uint32_t at = wave_append(&w.counters[C_COMPLEX], first);
-        if (first) w.complex_[at] = s;
     }
 }
 
