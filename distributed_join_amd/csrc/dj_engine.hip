@@ -601,12 +601,13 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
     // h_maxchain[8] = barriers of the previous batch with 9..16 events: while there are thousands of them the
     // register replay takes chains up to 16 (slower for everyone else, far cheaper than a wave per barrier)
     const bool wide = e->cx_force >= 0 ? (e->cx_force & 2) != 0 : hint[8] >= WIDE_ON;
-    // Bucketed form of the link and resolve passes (no atomic per event): for batches that are large enough to fill
-    // the buckets' runs, small enough for a bucket to fit the second pass's LDS (1024 keys on average, 2048 at most),
-    // and whose previous batch showed no long chains (a hot barrier overflows its bucket, and the batch then falls back to chains).
+    // Bucketed form of the link and resolve passes (no atomic per event): for batches that are large enough to give
+    // every compute unit a tile of the first pass (measured: 0.0913 -> 0.0890 ms per step at 262144 events, 0.137 ->
+    // 0.133 at 524288, 0.233 -> 0.217 at 2^20; 0.069 -> 0.073 at 131072), small enough for a bucket to fit the second
+    // pass's LDS (1024 keys on average, 2048 at most), and whose previous batch showed no long chains (a hot barrier overflows its bucket, and the batch then falls back to chains).
     const uint64_t slots = e->t.mask + 1;
     bool bucket = !serial_only && w.fused && !wide && n <= (1u << 20) && e->bucket_mode != 0 &&
-                  (e->bucket_mode == 1 || (n >= 32768 && hint[0] < 2048 && hint[1] < 512));
+                  (e->bucket_mode == 1 || (n >= 262144 && hint[0] < 2048 && hint[1] < 512));
     if (bucket) {
         uint32_t B = 16;
         while (B < BK_MAX_BUCKETS && (uint64_t)B * 1024 < n) B <<= 1;
@@ -618,13 +619,17 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
         bucket = (uint64_t)B * 1024 >= n;        // (a tiny table cannot spread a large batch)
     }
     if (bucket) {
-        const uint32_t tiles = grid_for(n, BK_TILE);
-#define DJ_LINKB(G) join_link_bucket_kernel<G><<<tiles, BK_BLOCK, 0, e->stream>>>(e->t, w, d_recs, n, pitch, d_status, d_payloads)
-        if (lanes <= 4) LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINKB(4)));
-        else if (lanes <= 8) LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINKB(8)));
-        else if (lanes <= 16) LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINKB(16)));
-        else if (lanes <= 32) LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINKB(32)));
-        else LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINKB(64)));
+        // events per thread of the first pass: about four keys per bucket and tile, and a tile per compute unit
+        const uint32_t ept = w.bbuckets >= 1024 ? 4 : w.bbuckets >= 512 ? 2 : 1;
+        const uint32_t tiles = grid_for(n, BK_BLOCK * ept);
+#define DJ_LINKB1(G, E) join_link_bucket_kernel<G, E><<<tiles, BK_BLOCK, 0, e->stream>>>(e->t, w, d_recs, n, pitch, d_status, d_payloads)
+#define DJ_LINKB(G) do { if (ept == 4) DJ_LINKB1(G, 4); else if (ept == 2) DJ_LINKB1(G, 2); else DJ_LINKB1(G, 1); } while (0)
+        if (lanes <= 4) LAUNCH(e, DJ_PROF_JOIN_LINK, DJ_LINKB(4));
+        else if (lanes <= 8) LAUNCH(e, DJ_PROF_JOIN_LINK, DJ_LINKB(8));
+        else if (lanes <= 16) LAUNCH(e, DJ_PROF_JOIN_LINK, DJ_LINKB(16));
+        else if (lanes <= 32) LAUNCH(e, DJ_PROF_JOIN_LINK, DJ_LINKB(32));
+        else LAUNCH(e, DJ_PROF_JOIN_LINK, DJ_LINKB(64));
+#undef DJ_LINKB1
 #undef DJ_LINKB
         LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_bucket_kernel<<<w.bbuckets, RB_T, 0, e->stream>>>(e->t, w, d_recs, n, now_ms, d_status)));
     } else {

@@ -509,7 +509,7 @@ join_resolve_kernel(Table t, Work w, uint32_t n, uint64_t now, int32_t* status) 
 // long-chain pass's list (slow, correct, and the host leaves the bucketed form from the next batch on, whose hints
 // show the long chain).
 // =====================================================================================
-constexpr int BK_TILE = 4096, BK_BLOCK = 1024, BK_MAX_BUCKETS = 1024;
+constexpr int BK_TILE = 4096, BK_BLOCK = 1024, BK_MAX_BUCKETS = 1024;      // BK_TILE: the largest tile (four events per thread)
 constexpr int RB_T = 512, RB_EPT = 4, RB_CAP = RB_T * RB_EPT, RB_H = RB_CAP;    // (as many cells as keys at most: a free cell is always left for a new slot)
 // key: slot inside its bucket's range << 35 | event index (24 bits) << 11 | has-max-wait << 10 | position (10 bits)
 __device__ inline uint64_t bkey_pack(uint32_t slot_local, uint32_t i, uint32_t pos, bool has_mw) {
@@ -517,9 +517,12 @@ __device__ inline uint64_t bkey_pack(uint32_t slot_local, uint32_t i, uint32_t p
 }
 __device__ inline uint32_t bkey_event(uint64_t k) { return (uint32_t)(k >> 11) & 0xFFFFFFu; }
 
-template <int G>
+// EPT events per thread: a tile is 1024 * EPT events.  The host picks EPT so that a batch makes about as many tiles as
+// the GPU has compute units and a tile still holds about four keys per bucket.
+template <int G, int EPT>
 __global__ void __launch_bounds__(BK_BLOCK) __attribute__((amdgpu_waves_per_eu(8)))
 join_link_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t pitch, int32_t* status, const uint8_t* payloads) {
+    constexpr uint32_t TILE = BK_BLOCK * EPT;
     __shared__ uint32_t hist[BK_MAX_BUCKETS], off[BK_MAX_BUCKETS], base[BK_MAX_BUCKETS];
     __shared__ uint64_t stage[BK_TILE];
     __shared__ uint16_t stage_b[BK_TILE];
@@ -537,12 +540,12 @@ join_link_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, ui
         w.counters_next[tix] = 0;
     }
     __syncthreads();
-    uint64_t key[4];
-    uint32_t bk[4], rank[4];
-    bool linked[4];
+    uint64_t key[EPT];
+    uint32_t bk[EPT], rank[EPT];
+    bool linked[EPT];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const uint32_t i = blockIdx.x * BK_TILE + wave * 256 + k * 64 + lane;
+    for (int k = 0; k < EPT; ++k) {
+        const uint32_t i = blockIdx.x * TILE + wave * (64 * EPT) + k * 64 + lane;
         uint64_t row_off = ~0ull;
         uint32_t row_len = 0;
         bool stores_meta = false;
@@ -584,9 +587,9 @@ join_link_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, ui
         }
         wave_copy_rows<G>(t, payloads, pitch, (uint64_t)i - lane, row_off, row_len);
         // a sample for the host: how ragged is the traffic (the batch's first 4 x 64 events)
-        if (blockIdx.x == 0 && wave == 0) {
+        if (blockIdx.x == 0 && wave * EPT + k < 4) {
             const uint64_t m = __ballot(stores_meta);
-            if (lane == 0) w.hint[4 + k] = (unsigned int)__popcll(m);
+            if (lane == 0) w.hint[4 + wave * EPT + k] = (unsigned int)__popcll(m);
         }
     }
     __syncthreads();
@@ -606,7 +609,7 @@ join_link_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, ui
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < EPT; ++k)
         if (linked[k]) {
             stage[off[bk[k]] + rank[k]] = key[k];
             stage_b[off[bk[k]] + rank[k]] = (uint16_t)bk[k];
