@@ -23,7 +23,7 @@ def per_kernel(path):
             continue
         name = name[4:].split("<")[0]
         name = name.replace("_kernel", "")
-        name = {"join_resolve_complex": "join_complex", "pop_due": "pop", "pop_due_track": "pop", "pop_ready": "pop", "pop_regions": "pop", "select_regions": "pop"}.get(name, name)
+        name = {"join_resolve_complex": "join_complex", "join_link_bucket": "join_link", "join_resolve_bucket": "join_resolve", "pop_due": "pop", "pop_due_track": "pop", "pop_ready": "pop", "pop_regions": "pop", "select_regions": "pop"}.get(name, name)
         acc[name].append(float(r["Counter_Value"]))
     return {k: sum(v) / len(v) for k, v in acc.items()}
 
