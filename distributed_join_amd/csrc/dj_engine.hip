@@ -396,7 +396,7 @@ extern "C" int dj_get_config(const dj_engine* e, dj_config* out) {
 }
 
 extern "C" int dj_set_hot_path(dj_engine* e, int mode) {
-    if (!e || mode < -1 || mode > 23 || (mode >= 8 && mode < 16 && (mode & 7) == 7)) return DJ_E_INVALID;
+    if (!e || mode < -1 || mode > 23) return DJ_E_INVALID;
     std::lock_guard<std::recursive_mutex> guard(e->mu);
     if (mode < 0) {
         e->bucket_mode = -1; e->fuse_off = 0; e->cx_force = -1;

@@ -203,3 +203,25 @@ def test_long_messages_when_the_arena_runs_out():
     s = e.stats()
     assert s["live"] == 0 and s["arena_units_free"] == s["arena_units_used"] - 1
     e.close()
+
+
+@pytest.mark.gpu
+def test_hot_path_modes_accepted_and_refused():
+    """dj_set_hot_path: -1, the pinned combinations 0..7, and 8 / 16 (+ the same low bits) for the bucketed join passes;
+    anything else is refused and leaves the engine as it was."""
+    from distributed_join_amd import capi
+    from distributed_join_amd.engine import Engine, EngineError
+    e = Engine(capacity_barriers=64, arena_bytes=1 << 20, max_count=8, payload_stride=64, max_batch=1024)
+    try:
+        for mode in (-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 15, 16, 17, 20, 23, -1):
+            e.set_hot_path(mode)
+        for mode in (-2, 24, 100):
+            with pytest.raises(EngineError):
+                e.set_hot_path(mode)
+        # still usable
+        rec = np.zeros(1, dtype=capi.FORK_REC)
+        rec[0]["fp_lo"], rec[0]["fp_hi"] = capi.fingerprint("m~1")
+        rec[0]["count"], rec[0]["deadline_ms"] = 2, 1_700_000_100_000
+        assert int(e.fork_batch(rec)[0]) == capi.DJ_FORK_CREATED
+    finally:
+        e.close()
