@@ -604,10 +604,13 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
     // Bucketed form of the link and resolve passes (no atomic per event): for batches that are large enough to give
     // every compute unit a tile of the first pass (measured: 0.0913 -> 0.0890 ms per step at 262144 events, 0.137 ->
     // 0.133 at 524288, 0.233 -> 0.217 at 2^20; 0.069 -> 0.073 at 131072), small enough for a bucket to fit the second
-    // pass's LDS (1024 keys on average, 2048 at most), and whose previous batch showed no long chains (a hot barrier overflows its bucket, and the batch then falls back to chains).
+    // pass's LDS (1024 keys on average, 2048 at most), on tables of up to 2^22 slots (the second pass finds the lines
+    // that the first one fetched in the 256 MB Infinity Cache as long as not much more than the table competes for it:
+    // with batches applied in pieces of 2^20 events the bucketed form gained 7 % on a table of 2^21 slots, lost 1 % at
+    // 2^22 and 9 % at 2^23 and 2^25), and whose previous batch showed no long chains (a hot barrier overflows its bucket, and the batch then falls back to chains).
     const uint64_t slots = e->t.mask + 1;
     bool bucket = !serial_only && w.fused && !wide && n <= (1u << 20) && e->bucket_mode != 0 &&
-                  (e->bucket_mode == 1 || (n >= 262144 && hint[0] < 2048 && hint[1] < 512));
+                  (e->bucket_mode == 1 || (n >= 262144 && slots <= (1ull << 22) && hint[0] < 2048 && hint[1] < 512));
     if (bucket) {
         uint32_t B = 16;
         while (B < BK_MAX_BUCKETS && (uint64_t)B * 1024 < n) B <<= 1;

@@ -313,7 +313,7 @@ class Engine:
         register replay of short chains, 0 / 1 the 8-event one; +4 keeps the separate message-copy pass where
         the link pass could copy the messages itself; +8 never runs the bucketed form of the link and resolve passes,
         +16 runs it wherever it applies (by itself the engine uses it for batches of 262144 to 2^20 events without long
-        chains); 8 and 16 alone leave the other choices automatic (same results in every mode)."""
+        chains on tables of up to 2^22 slots); 8 and 16 alone leave the other choices automatic (same results in every mode)."""
         self._check(self.L.dj_set_hot_path(self.h, int(mode)))
 
     def set_sweep_path(self, mode):

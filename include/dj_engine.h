@@ -333,8 +333,11 @@ int dj_checkpoint_load(dj_engine* e, const char* path);
  * short chains has a form for up to 8 events and one for up to 16, picked from the previous batch:
  * adding 2 to the mode (2 serial, 3 parallel) pins the second, 0 and 1 pin the first.  Messages that
  * fit a payload row are copied into the table by the first pass over the events itself when the serial
- * form runs; adding 4 (modes 4..7) keeps the separate copy pass that the other cases use.  No reference
- * counterpart. */
+ * form runs; adding 4 (modes 4..7) keeps the separate copy pass that the other cases use.  The first two
+ * passes over a join batch also have a bucketed form without an atomic per event, which the engine picks for
+ * batches of 262144 to 2^20 events on tables of up to 2^22 slots whose previous batch showed no long chains: adding
+ * 8 never runs it, adding 16 runs it wherever it applies (8 and 16 alone leave the other choices automatic).
+ * Valid modes: -1 .. 23.  No reference counterpart. */
 int dj_set_hot_path(dj_engine* e, int mode);
 
 /* How a sweep finds what is due.  The reference pops a sorted set by score (redis.clj:283-289), which costs
