@@ -197,8 +197,8 @@ int dj_join_batch(dj_engine* e, uint32_t n, const dj_join_rec* d_recs,
                   const uint8_t* d_payloads, uint64_t pitch, uint64_t now_ms, int32_t* d_status);
 
 /* dj_join_batch for callers that must not allocate (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same results, same
- * kernels as dj_join_batch; the per-batch work arrays (link words, destinations, event-to-slot map, list of
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same results, the chain
+ * form of dj_join_batch's kernels (never the bucketed one, whose key buffers belong to the engine); the per-batch work arrays (link words, destinations, event-to-slot map, list of
  * long chains, counters: 24 bytes per event) live in a device array of the library's code object instead of
  * memory the engine allocated, 1.5 MiB per GPU that stays until the process ends.  Limit: n <=
  * DJ_STATIC_JOIN_MAX events per call (DJ_E_TOO_LARGE beyond).  The call itself allocates and frees nothing
