@@ -60,6 +60,7 @@ struct dj_engine {
     std::recursive_mutex mu;     // entry points serialise themselves: callers may share an engine between threads
     Slot* slots_alt;             // second table for dj_compact (always all-empty between calls)
     uint64_t* q_alt;
+    uint32_t n_cus;              // compute units of the device
     int bucket_mode;             // -1: the bucketed join passes where they pay; 0: never; 1: wherever they apply (tests)
     int fuse_off;                // 1: the link pass never copies messages itself (dj_set_hot_path mode + 4: tests of the separate copy pass)
     int cx_force;                // -1: automatic; else bit 0: parallel hot-barrier kernels, bit 1: wide register replay (tests)
@@ -367,6 +368,11 @@ extern "C" int dj_create(const dj_config* cfg, dj_engine** out) {
     e->cx_force = -1;
     e->fuse_off = 0;
     e->bucket_mode = -1;
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || cus < 1) cus = 256;
+        e->n_cus = (uint32_t)cus;
+    }
     e->scratch_ptr = nullptr;
     for (int k = 0; k < DJ_PROF_KERNELS; ++k) { e->ev_start[k] = nullptr; e->ev_stop[k] = nullptr; e->ev_used[k] = 0; }
     int rc = create_impl(e);
@@ -604,12 +610,13 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
     // Bucketed form of the link and resolve passes (no atomic per event): for batches that are large enough to give
     // every compute unit a tile of the first pass (measured: 0.0913 -> 0.0890 ms per step at 262144 events, 0.137 ->
     // 0.133 at 524288, 0.233 -> 0.217 at 2^20; 0.069 -> 0.073 at 131072), small enough for a bucket to fit the second
-    // pass's LDS (1024 keys on average, 2048 at most), on tables of up to 2^22 slots (the second pass finds the lines
+    // pass's LDS (2048 keys at most; up to 1280 on average, so that a rank's share of a routed batch of 2^20 events per
+    // rank, which comes a little above or below 2^20, stays in this form), on tables of up to 2^22 slots (the second pass finds the lines
     // that the first one fetched in the 256 MB Infinity Cache as long as not much more than the table competes for it:
     // with batches applied in pieces of 2^20 events the bucketed form gained 7 % on a table of 2^21 slots, lost 1 % at
     // 2^22 and 9 % at 2^23 and 2^25), and whose previous batch showed no long chains (a hot barrier overflows its bucket, and the batch then falls back to chains).
     const uint64_t slots = e->t.mask + 1;
-    bool bucket = !serial_only && w.fused && !wide && n <= (1u << 20) && e->bucket_mode != 0 &&
+    bool bucket = !serial_only && w.fused && !wide && n <= BK_MAX_BUCKETS * BK_MEAN_MAX && e->bucket_mode != 0 &&
                   (e->bucket_mode == 1 || (n >= 262144 && slots <= (1ull << 22) && hint[0] < 2048 && hint[1] < 512));
     if (bucket) {
         uint32_t B = 16;
@@ -619,14 +626,24 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
         while ((slots >> shift) > B) ++shift;
         w.bbuckets = B;
         w.bshift = shift;
-        bucket = (uint64_t)B * 1024 >= n;        // (a tiny table cannot spread a large batch)
+        bucket = (uint64_t)B * BK_MEAN_MAX >= n;        // (a tiny table cannot spread a large batch)
+    }
+    // equal tiles of the first pass: one per compute unit (two above 4096 events per unit; a unit holds two blocks),
+    // none below 1024 events; 2^20 events on 256 units: 256 tiles of 4096.  A batch of 257 tiles of 4096 took
+    // 108 us where 256 took 82.
+    uint32_t tiles = 0, tile_events = 0, ept = 0;
+    if (bucket) {
+        const uint32_t most = e->n_cus * (n > (uint64_t)e->n_cus * BK_TILE ? 2u : 1u);
+        tiles = grid_for(n, BK_BLOCK);
+        if (tiles > most) tiles = most;
+        tile_events = (uint32_t)(((n + tiles - 1) / tiles + 63) & ~63ull);
+        tiles = grid_for(n, tile_events);
+        ept = (tile_events + BK_BLOCK - 1) / BK_BLOCK;
+        bucket = ept <= 4;                              // (a GPU with few compute units: the chain form)
     }
     if (bucket) {
-        // events per thread of the first pass: about four keys per bucket and tile, and a tile per compute unit
-        const uint32_t ept = w.bbuckets >= 1024 ? 4 : w.bbuckets >= 512 ? 2 : 1;
-        const uint32_t tiles = grid_for(n, BK_BLOCK * ept);
-#define DJ_LINKB1(G, E) join_link_bucket_kernel<G, E><<<tiles, BK_BLOCK, 0, e->stream>>>(e->t, w, d_recs, n, pitch, d_status, d_payloads)
-#define DJ_LINKB(G) do { if (ept == 4) DJ_LINKB1(G, 4); else if (ept == 2) DJ_LINKB1(G, 2); else DJ_LINKB1(G, 1); } while (0)
+#define DJ_LINKB1(G, E) join_link_bucket_kernel<G, E><<<tiles, BK_BLOCK, 0, e->stream>>>(e->t, w, d_recs, n, tile_events, pitch, d_status, d_payloads)
+#define DJ_LINKB(G) do { if (ept == 4) DJ_LINKB1(G, 4); else if (ept == 3) DJ_LINKB1(G, 3); else if (ept == 2) DJ_LINKB1(G, 2); else DJ_LINKB1(G, 1); } while (0)
         if (lanes <= 4) LAUNCH(e, DJ_PROF_JOIN_LINK, DJ_LINKB(4));
         else if (lanes <= 8) LAUNCH(e, DJ_PROF_JOIN_LINK, DJ_LINKB(8));
         else if (lanes <= 16) LAUNCH(e, DJ_PROF_JOIN_LINK, DJ_LINKB(16));

@@ -510,6 +510,7 @@ join_resolve_kernel(Table t, Work w, uint32_t n, uint64_t now, int32_t* status) 
 // show the long chain).
 // =====================================================================================
 constexpr int BK_TILE = 4096, BK_BLOCK = 1024, BK_MAX_BUCKETS = 1024;      // BK_TILE: the largest tile (four events per thread)
+constexpr uint32_t BK_MEAN_MAX = 1280;     // events per bucket on average at most (a bucket holds RB_CAP; a batch of random keys spreads with a deviation of about 36)
 constexpr int RB_T = 512, RB_EPT = 4, RB_CAP = RB_T * RB_EPT, RB_H = RB_CAP;    // (as many cells as keys at most: a free cell is always left for a new slot)
 // key: slot inside its bucket's range << 35 | event index (24 bits) << 11 | has-max-wait << 10 | position (10 bits)
 __device__ inline uint64_t bkey_pack(uint32_t slot_local, uint32_t i, uint32_t pos, bool has_mw) {
@@ -517,12 +518,16 @@ __device__ inline uint64_t bkey_pack(uint32_t slot_local, uint32_t i, uint32_t p
 }
 __device__ inline uint32_t bkey_event(uint64_t k) { return (uint32_t)(k >> 11) & 0xFFFFFFu; }
 
-// EPT events per thread: a tile is 1024 * EPT events.  The host picks EPT so that a batch makes about as many tiles as
-// the GPU has compute units and a tile still holds about four keys per bucket.
+// A tile is tile_events consecutive events (a multiple of 64, at most 1024 * EPT): the host cuts a batch into equal
+// tiles, one or two per compute unit (a thread works through its events one after the other, so that a tile more than
+// the GPU holds at once, or one longer than the others, costs a whole extra round), and a tile still holds two to four
+// keys per bucket.  Round k of a tile takes its events k * 1024 .. k * 1024 + 1023.
 template <int G, int EPT>
 __global__ void __launch_bounds__(BK_BLOCK) __attribute__((amdgpu_waves_per_eu(8)))
-join_link_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t pitch, int32_t* status, const uint8_t* payloads) {
-    constexpr uint32_t TILE = BK_BLOCK * EPT;
+join_link_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint32_t tile_events, uint64_t pitch, int32_t* status,
+                        const uint8_t* payloads) {
+    const uint32_t tile_base = blockIdx.x * tile_events;
+    const uint32_t tile_end = n - tile_base < tile_events ? n : tile_base + tile_events;
     __shared__ uint32_t hist[BK_MAX_BUCKETS], off[BK_MAX_BUCKETS], base[BK_MAX_BUCKETS];
     __shared__ uint64_t stage[BK_TILE];
     __shared__ uint16_t stage_b[BK_TILE];
@@ -545,12 +550,12 @@ join_link_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, ui
     bool linked[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
-        const uint32_t i = blockIdx.x * TILE + wave * (64 * EPT) + k * 64 + lane;
+        const uint32_t i = tile_base + k * BK_BLOCK + tix;
         uint64_t row_off = ~0ull;
         uint32_t row_len = 0;
         bool stores_meta = false;
         key[k] = 0; bk[k] = 0; rank[k] = 0; linked[k] = false;
-        if (i < n) {
+        if (i < tile_end) {
             const ulonglong2 a = reinterpret_cast<const ulonglong2*>(recs)[2 * (size_t)i];
             const uint4 b = reinterpret_cast<const uint4*>(recs)[2 * (size_t)i + 1];  // position, len, max_wait, -
             int32_t st = 0;
@@ -587,9 +592,9 @@ join_link_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, ui
         }
         wave_copy_rows<G>(t, payloads, pitch, (uint64_t)i - lane, row_off, row_len);
         // a sample for the host: how ragged is the traffic (the batch's first 4 x 64 events)
-        if (blockIdx.x == 0 && wave * EPT + k < 4) {
+        if (blockIdx.x == 0 && k == 0 && wave < 4) {
             const uint64_t m = __ballot(stores_meta);
-            if (lane == 0) w.hint[4 + wave * EPT + k] = (unsigned int)__popcll(m);
+            if (lane == 0) w.hint[4 + wave] = (unsigned int)__popcll(m);
         }
     }
     __syncthreads();

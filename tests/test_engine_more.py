@@ -156,15 +156,17 @@ def test_config3_shape_scaled(oracle_lib):
         e.close()
 
 
-def test_config2_full_size_properties():
+@pytest.mark.parametrize("uneven", [0, 200_000])
+def test_config2_full_size_properties(uneven):
     """BASELINE config #2 at full size (1 M barriers x count 8, 64 B messages, 8 M joins, batches of
-    1 M): every barrier fires exactly once, COMPLETE, with every byte where the generator put it."""
+    1 M): every barrier fires exactly once, COMPLETE, with every byte where the generator put it.
+    uneven: batches of 1 M + and - that many events in turn (what a rank of a routed job receives is never exactly 2^20)."""
     import torch
     nb, c, P = 1 << 20, 8, 64
     rng = np.random.default_rng(22)
     ids = [f"j{b:x}~t{b:x}" for b in range(nb)]
     fps = capi.fingerprint_many(ids)
-    e = _engine(capacity_barriers=nb, arena_bytes=nb * 640 + (64 << 20), max_count=c, payload_stride=P, max_batch=nb)
+    e = _engine(capacity_barriers=nb, arena_bytes=nb * 640 + (64 << 20), max_count=c, payload_stride=P, max_batch=nb + uneven)
     dev = e.device
     try:
         frecs = np.zeros(nb, dtype=capi.FORK_REC)
@@ -180,11 +182,15 @@ def test_config2_full_size_properties():
         order = np.lexsort((fps[:, 1], fps[:, 0]))
         sorted_lo, sorted_hi = fps[order, 0], fps[order, 1]
         total_complete = 0
+        cuts = [0]
+        for k in range(c):
+            cuts.append(cuts[-1] + nb + (uneven if k % 2 == 0 else -uneven))
+        assert cuts[-1] == nb * c
         for k in range(c):
             now = T0 + 1 + k
-            part = ev[k * nb:(k + 1) * nb]
+            part = ev[cuts[k]:cuts[k + 1]]
             jb, jp = part // c, part % c
-            recs = np.zeros(nb, dtype=capi.JOIN_REC)
+            recs = np.zeros(len(part), dtype=capi.JOIN_REC)
             recs["fp_lo"], recs["fp_hi"], recs["position"], recs["len"] = fps[jb, 0], fps[jb, 1], jp, P
             st = e.join_batch(recs, payload_bytes(jb, jp, jb * 0, P), now)
             assert np.isin(st, [capi.DJ_JOIN_WAITING, capi.DJ_JOIN_COMPLETE]).all()

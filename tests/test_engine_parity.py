@@ -140,6 +140,31 @@ def test_thousands_of_barriers_with_ten_events_a_batch(oracle_lib, hot_mode):
         e.close()
 
 
+@pytest.mark.parametrize("hot_mode", [-1, 16])
+def test_batch_a_little_above_a_million_events(oracle_lib, hot_mode):
+    """1.2 M events in one batch on 300 000 barriers (a rank of a routed job with 2^20 events per rank receives a
+    little more or less than 2^20): the bucketed passes hold up to 1280 events per bucket on average.  Statuses
+    element by element, then the stored state of a sample of the barriers."""
+    rng = np.random.default_rng(77)
+    nb, n = 300_000, 1_200_000
+    ids = [f"big{b:x}~t{b:x}" for b in range(nb)]
+    counts = rng.integers(2, 10, nb)
+    e, o, d = make_pair(oracle_lib, ids, 64, max_count=16, arena=1 << 30, max_batch=1 << 21, hot_mode=hot_mode)
+    try:
+        now = T0 + 5
+        d.fork(np.arange(nb), counts, np.full(nb, now + 60_000))
+        for r in range(2):
+            now += 7
+            jb = rng.integers(0, nb + 1000, n) % nb
+            pos = (rng.random(n) * counts[jb]).astype(np.int64)
+            pos[rng.random(n) < 0.01] += 1000          # out of range
+            jmw = np.where(rng.random(n) < 0.1, rng.integers(1, 5, n), 0)
+            d.join(jb, pos, np.full(n, 64), jmw, payload_bytes(jb, pos % 1024, np.full(n, r + 1) + np.arange(n), 64), now)
+        d.check_all_snapshots(which=rng.choice(nb, 2000, replace=False))
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("hot_mode", [-1, 0, 1, 4, 16])
 def test_hot_barrier_long_chains(oracle_lib, hot_mode):
     rng = np.random.default_rng(2)

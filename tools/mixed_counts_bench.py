@@ -14,7 +14,7 @@ def main():
     import torch
     from distributed_join_amd import capi
     from distributed_join_amd.engine import Engine
-    # usage: mixed_counts_bench.py [barriers [fixed-count [hot-path-mode]]]
+    # usage: mixed_counts_bench.py [barriers [fixed-count [hot-path-mode [events-per-batch]]]]
     nb, P = (int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20), 64
     fixed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     rng = np.random.default_rng(3)
@@ -42,12 +42,12 @@ def main():
     jrecs = np.zeros(total, dtype=capi.JOIN_REC)
     jrecs["fp_lo"], jrecs["fp_hi"], jrecs["position"], jrecs["len"] = fps[b_of, 0], fps[b_of, 1], p_of, P
     d_j = torch.from_numpy(jrecs.view(np.uint8).reshape(-1).copy()).to(dev)
-    d_pay = torch.randint(0, 256, (1 << 20, P), dtype=torch.uint8, device=dev)
+    batch = int(sys.argv[4]) if len(sys.argv) > 4 else 1 << 20
+    d_pay = torch.randint(0, 256, (batch, P), dtype=torch.uint8, device=dev)
     d_st = e.empty((1 << 21) * 4)
     cap_c, cap_p = nb, total
     d_conts, d_lens, d_out, d_res, d_ack = e.empty(cap_c * 64), e.empty(cap_p * 4), e.empty(cap_p * P), e.empty(16), e.empty(cap_c * 4)
     torch.cuda.synchronize()
-    batch = 1 << 20
     for job in range(3):
         acc = {}
         if job == 2:
@@ -65,7 +65,7 @@ def main():
                     acc.setdefault(name, []).append(ms)
         e.sync()
         assert e.stats()["live"] == 0
-    print(f"{nb} barriers, {total} events, counts {'Zipf(1) on [2, 64]' if not fixed else fixed}, {P} B messages; per launch (ms):")
+    print(f"{nb} barriers, {total} events in batches of {batch}, counts {'Zipf(1) on [2, 64]' if not fixed else fixed}, {P} B messages; per launch (ms):")
     for name, v in acc.items():
         print(f"  {name:14s} avg {sum(v) / len(v):.4f}  x{len(v)}  total {sum(v):.3f}")
     e.close()
