@@ -608,8 +608,9 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
     // register replay takes chains up to 16 (slower for everyone else, far cheaper than a wave per barrier)
     const bool wide = e->cx_force >= 0 ? (e->cx_force & 2) != 0 : hint[8] >= WIDE_ON;
     // Bucketed form of the link and resolve passes (no atomic per event): for batches that are large enough to give
-    // every compute unit a tile of the first pass (measured: 0.0913 -> 0.0890 ms per step at 262144 events, 0.137 ->
-    // 0.133 at 524288, 0.233 -> 0.217 at 2^20; 0.069 -> 0.073 at 131072), small enough for a bucket to fit the second
+    // every compute unit a tile of the first pass (measured, link + resolve pass in us, chain form -> bucketed: 36.8 ->
+    // 39.8 at 131072 events, 45.1 -> 41.9 at 196608, 51.2 -> 48.1 at 262144, 64.6 -> 62.1 at 393216, 135 -> 119 at 2^20;
+    // buckets of 512 to 1024 events on average up to 2^20), small enough for a bucket to fit the second
     // pass's LDS (2048 keys at most; up to 1280 on average, so that a rank's share of a routed batch of 2^20 events per
     // rank, which comes a little above or below 2^20, stays in this form), on tables of up to 2^22 slots (the second pass finds the lines
     // that the first one fetched in the 256 MB Infinity Cache as long as not much more than the table competes for it:
@@ -617,10 +618,10 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
     // 2^22 and 9 % at 2^23 and 2^25), and whose previous batch showed no long chains (a hot barrier overflows its bucket, and the batch then falls back to chains).
     const uint64_t slots = e->t.mask + 1;
     bool bucket = !serial_only && w.fused && !wide && n <= BK_MAX_BUCKETS * BK_MEAN_MAX && e->bucket_mode != 0 &&
-                  (e->bucket_mode == 1 || (n >= 262144 && slots <= (1ull << 22) && hint[0] < 2048 && hint[1] < 512));
+                  (e->bucket_mode == 1 || (n >= 196608 && slots <= (1ull << 22) && hint[0] < 2048 && hint[1] < 512));
     if (bucket) {
         uint32_t B = 16;
-        while (B < BK_MAX_BUCKETS && (uint64_t)B * 1024 < n) B <<= 1;
+        while (B < BK_MAX_BUCKETS && (uint64_t)B * 512 < n) B <<= 1;
         while (B > 1 && (uint64_t)B * 4 > slots) B >>= 1;
         uint32_t shift = 0;
         while ((slots >> shift) > B) ++shift;

@@ -312,7 +312,7 @@ class Engine:
         """-1 automatic, 0 serial, 1 parallel kernels for barriers with long chains; +2 pins the 16-event
         register replay of short chains, 0 / 1 the 8-event one; +4 keeps the separate message-copy pass where
         the link pass could copy the messages itself; +8 never runs the bucketed form of the link and resolve passes,
-        +16 runs it wherever it applies (by itself the engine uses it for batches of 262144 to 1310720 events without long
+        +16 runs it wherever it applies (by itself the engine uses it for batches of 196608 to 1310720 events without long
         chains on tables of up to 2^22 slots); 8 and 16 alone leave the other choices automatic (same results in every mode)."""
         self._check(self.L.dj_set_hot_path(self.h, int(mode)))
 

@@ -335,7 +335,7 @@ int dj_checkpoint_load(dj_engine* e, const char* path);
  * fit a payload row are copied into the table by the first pass over the events itself when the serial
  * form runs; adding 4 (modes 4..7) keeps the separate copy pass that the other cases use.  The first two
  * passes over a join batch also have a bucketed form without an atomic per event, which the engine picks for
- * batches of 262144 to 1310720 events on tables of up to 2^22 slots whose previous batch showed no long chains: adding
+ * batches of 196608 to 1310720 events on tables of up to 2^22 slots whose previous batch showed no long chains: adding
  * 8 never runs it, adding 16 runs it wherever it applies (8 and 16 alone leave the other choices automatic).
  * Valid modes: -1 .. 23.  No reference counterpart. */
 int dj_set_hot_path(dj_engine* e, int mode);

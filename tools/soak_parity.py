@@ -43,7 +43,7 @@ def main():
          dict(recount=(2, 300), fail_every=2, hot=5), dict()),
         ("the same with long messages", 800 * scale, (1, 91), 64, 12, 8000 * scale,
          dict(long_to=4096, recount=(1, 90), fail_every=2), dict(max_message=4096)),
-        # the bucketed join passes pinned (by themselves they start at 262144 events per batch)
+        # the bucketed join passes pinned (by themselves they start at 196608 events per batch)
         ("small counts, bucketed passes", 4000 * scale, (1, 9), 64, 20, 30000 * scale, dict(unknown=50), dict(hot_mode=16)),
         ("hot barrier, bucketed passes", 2000 * scale, (2, 65), 64, 15, 40000 * scale, dict(hot=7), dict(hot_mode=16)),
         ("ten events per barrier and batch, bucketed passes", 6000, (2, 17), 64, 6, 60000 * scale, dict(), dict(hot_mode=16)),
