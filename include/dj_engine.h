@@ -270,8 +270,10 @@ int dj_queue_scores(dj_engine* e, uint64_t fp_lo, uint64_t fp_hi,
 
 /* ---- the remaining commands of the store namespace, one key at a time ----------------------------
  * With these, every public function of distributed-join.redis (redis.clj:90-300) has an entry point of its own,
- * so a host can keep core.clj as it is and replace only the namespace behind it (INTEGRATION.md lists the
- * thirteen).  The batch calls above fuse what core.clj does between two of these commands; these do not. */
+ * so a host can keep core.clj as it is and replace only the namespace behind it (the thirteen: fork,
+ * update-metadata, join, complete, join-metadata, all-joins, all-joins-status, store-in-publish-queue,
+ * store-nearest-in-publish-queue, all-publish-messages, get-unprocessed-publish-messages, get-publish-date, shutdown).
+ * The batch calls above fuse what core.clj does between two of these commands; these do not. */
 
 /* redis/complete (redis.clj:191-205, Lua complete-if-no-update redis.clj:162-189): deletes the barrier (metadata,
  * messages, both timestamps, both queue entries) when no join arrived since the last redis/all-joins, else
