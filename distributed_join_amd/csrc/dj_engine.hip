@@ -75,6 +75,8 @@ struct dj_engine {
     unsigned int* d_counters;    // 2 x C_COUNT
     unsigned int* d_fork_contested;      // 2 words: this fork batch's and the next one's (see Work::fork_contested)
     int fork_bank;
+    unsigned long long* d_live;  // 2 words: live keys counted by this compaction and by the next one (each zeroes the other's)
+    int live_bank;
     unsigned long long* d_sweep; // 2 x S_COUNT
     unsigned long long* d_due;   // the two banks of the sweep's scan bound (Table::due_min points to one of them)
     // optional per-kernel timing (dj_profile_enable): one event pair per kernel id
@@ -303,6 +305,9 @@ static int create_impl(dj_engine* e) {
     ALLOC(e, w.regions, (slots >> REGION_SHIFT) * 4);
     ALLOC(e, e->d_fork_contested, 2 * 4);
     HIP_TRY(e, hipMemsetAsync(e->d_fork_contested, 0, 2 * 4, e->stream));
+    ALLOC(e, e->d_live, 2 * 8);
+    HIP_TRY(e, hipMemsetAsync(e->d_live, 0, 2 * 8, e->stream));
+    e->live_bank = 0;
     ALLOC(e, e->d_counters, 2 * C_COUNT * 4);
     HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 2 * C_COUNT * 4, e->stream));
     ALLOC(e, w.bkeys, (size_t)BK_MAX_BUCKETS * RB_CAP * 8);
@@ -471,19 +476,16 @@ static uint32_t scan_blocks(const dj_engine* e) {
 // fingerprint before use.  compact_start queues the work and the read-back of the live count;
 // compact_finish waits for the count (or, with wait = false, takes it only if it has arrived).
 static int compact_start(dj_engine* e) {
-    const uint64_t slots = e->t.mask + 1;
     Table to = e->t;
     to.slots = e->slots_alt;
     to.q = e->q_alt;
     if (e->profiling) (void)hipEventRecord(e->ev_start[DJ_PROF_COMPACT], e->stream);
-    HIP_TRY(e, hipMemsetAsync(e->t.stat, 0, 4 * 8, e->stream));
-    rebuild_kernel<<<scan_blocks(e), 256, 0, e->stream>>>(e->t, to, e->t.stat);
-    HIP_TRY(e, hipGetLastError());
-    HIP_TRY(e, hipMemsetAsync(e->t.slots, 0, slots * sizeof(Slot), e->stream));
-    HIP_TRY(e, hipMemsetAsync(e->t.q, 0xFF, slots * 8, e->stream));
-    HIP_TRY(e, hipMemsetAsync(e->t.ready_ovf, 1, 4, e->stream));       // the ready list names slots of the old table: the next sweep scans
+    unsigned long long* live = e->d_live + e->live_bank;
+    e->live_bank ^= 1;
+    rebuild_kernel<<<scan_blocks(e), 256, 0, e->stream>>>(e->t, to, live, e->d_live + e->live_bank);
+    HIP_TRY(e, hipGetLastError());      // (the kernel leaves the old table all-empty and marks the ready list as incomplete)
     if (e->profiling) { (void)hipEventRecord(e->ev_stop[DJ_PROF_COMPACT], e->stream); e->ev_used[DJ_PROF_COMPACT] = 1; }
-    HIP_TRY(e, hipMemcpyAsync(e->h_maxchain + 2, e->t.stat, 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipMemcpyAsync(e->h_maxchain + 2, live, 8, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipEventRecord(e->compact_ev, e->stream));
     e->slots_alt = e->t.slots;
     e->q_alt = e->t.q;

@@ -2157,19 +2157,30 @@ __global__ void __launch_bounds__(256) list_unprocessed_kernel(Table t, uint64_t
 // Table hygiene: deleted barriers leave tombstones, and a lookup of an absent key only stops at a
 // never-used slot.  rebuild re-inserts every live slot of `from` into the empty table `to`
 // (same size); the host then swaps the two and clears the old one.  live[0] += live slots.
-__global__ void __launch_bounds__(256) rebuild_kernel(Table from, Table to, unsigned long long* live) {
+__global__ void __launch_bounds__(256) rebuild_kernel(Table from, Table to, unsigned long long* live, unsigned long long* live_next) {
     const uint64_t nslots = from.mask + 1;
     unsigned long long mine = 0;
+    // the ready list names slots of the old table: the next sweep scans; the next compaction counts from zero
+    if (blockIdx.x == 0 && threadIdx.x == 0) { a_store(from.ready_ovf, 1u); *live_next = 0; }
     for (uint64_t s = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; s < nslots; s += (uint64_t)gridDim.x * blockDim.x) {
+        // The old table is left all-empty on the way (it is the next compaction's target): a never-used slot is all
+        // zeros already, a deleted one all zeros but the first half of its key (clear_slot), and both have no queue
+        // entry; a live slot is cleared after it has moved.
+        const ulonglong2 key = *reinterpret_cast<const ulonglong2*>(&from.slots[s]);
+        if (key.x == FP_EMPTY) continue;
+        if (key.x == FP_TOMB) { from.slots[s].fp_lo = FP_EMPTY; continue; }
         const Slot sl = from.slots[s];
-        if (sl.fp_lo < 2) continue;
+        const uint64_t qv = from.q[s];
+        ulonglong2* line = reinterpret_cast<ulonglong2*>(&from.slots[s]);
+        line[0] = line[1] = line[2] = line[3] = make_ulonglong2(0, 0);
+        from.q[s] = Q_NONE;
         bool created;
         const int64_t d = find_or_claim(to, sl.fp_lo, sl.fp_hi, &created);
         if (d < 0) continue;   // cannot happen: `to` has as many slots as `from` has live keys at most
         Slot* dl = &to.slots[d];
         dl->count = sl.count; dl->meta = sl.meta; dl->slab = sl.slab; dl->chain = 0;
         dl->deadline = sl.deadline; dl->join_ts = sl.join_ts; dl->join_ts_read = sl.join_ts_read; dl->bits = sl.bits;
-        to.q[d] = from.q[s];
+        to.q[d] = qv;
         ++mine;
     }
     for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off);
