@@ -350,6 +350,7 @@ def main():
     res_i = [0]
     d_status = eng.empty(max(recv_cap, nb * 2) * 4)
     d_ack_status = eng.empty(cap_conts * 4)
+    d_status_home = torch.empty(max(batch, nb), dtype=torch.int32, device=dev)     # routed mode: the answers to this rank's own records
     es = eng.torch_stream()
 
     router = None
@@ -379,12 +380,18 @@ def main():
                 lo_f = (1 if a.hot_frac > 0 else 1000 if a.zipf_frac > 0 else 0) if k >= steps_per_job else 0
                 eng.fork_batch_dev(nb - lo_f, fork_recs[lo_f:], d_status)
             else:
+                # every record's answer goes back to the rank that submitted it (the reference answers every request):
+                # the engine writes a piece's statuses into the router's buffer, the router returns them per piece and
+                # puts them into this rank's submission order at the end (d_status_home)
                 h = pending_fork.pop(0) if pending_fork else router.start(fork_recs, None, nb)
                 r_recs, _, n_in = router.finish(h)
-                eng.fork_batch_dev(n_in, r_recs, d_status)
+                eng.fork_batch_dev(n_in, r_recs, router.status_buffer(h))
+                router.return_statuses(h)
                 while router.more(h):           # a rank that owns more than its buffer holds takes the rest in rounds
                     r_recs, _, n_in = router.next_round(h)
-                    eng.fork_batch_dev(n_in, r_recs, d_status)
+                    eng.fork_batch_dev(n_in, r_recs, router.status_buffer(h))
+                    router.return_statuses(h)
+                router.statuses(h, d_status_home, wait_stream=router.comm_stream)
                 router.release(h)
         lo = s * batch
         if router is None:
@@ -392,10 +399,13 @@ def main():
         else:
             h = pending.pop(0) if pending else start_route(k)
             r_recs, r_pay, n_in = router.finish(h)
-            eng.join_batch_dev(n_in, r_recs, r_pay, pitch, now[0], d_status)
+            eng.join_batch_dev(n_in, r_recs, r_pay, pitch, now[0], router.status_buffer(h))
+            router.return_statuses(h)
             while router.more(h):               # a hot key's owner takes its rows in several rounds (all ranks take part)
                 r_recs, r_pay, n_in = router.next_round(h)
-                eng.join_batch_dev(n_in, r_recs, r_pay, pitch, now[0], d_status)
+                eng.join_batch_dev(n_in, r_recs, r_pay, pitch, now[0], router.status_buffer(h))
+                router.return_statuses(h)
+            router.statuses(h, d_status_home, wait_stream=router.comm_stream)
             router.release(h)
         d_res = d_res_all[res_i[0] % d_res_all.shape[0]]
         res_i[0] += 1

@@ -156,8 +156,10 @@
         (do (if previous (.put forks fp previous) (.remove forks fp))    ; a refused fork leaves the barrier as it was
             (throw (ex-info "Database failure(s)" {:causes [(str "engine limit reached: " (.getInt status 0))]})))))))
 
-(defn join-status
-  "record: the Join map (store.clj:19-28).  Deferred of the engine's DJ_JOIN_* status of the event."
+(defn join-word
+  "record: the Join map (store.clj:19-28).  Deferred of the engine's status word of the event: DJ_JOIN_* in the low
+  byte and, once dj_set_join_hlen is on (the namespace distributed-join.redis turns it on), HLEN of the barrier's
+  hash after the event above it (DJ_JOIN_HLEN_SHIFT = 8)."
   [record]
   (deferred/future
     (let [[lo hi] (fingerprint (:barrier-id record))
@@ -171,6 +173,11 @@
           status (Memory. 4)]
       (check (native-int dj "dj_batcher_join_wait" @batcher rec message status) "dj_batcher_join_wait")
       (.getInt status 0))))
+
+(defn join-status
+  "Deferred of the engine's DJ_JOIN_* status of the event (DJ_JOIN_STATUS of its status word)."
+  [record]
+  (deferred/chain (join-word record) #(bit-and (int %) 0xFF)))
 
 (defn join-failure
   "The error deferred of a refused join (the texts of redis.clj:152-153), nil for a status that stored the message."

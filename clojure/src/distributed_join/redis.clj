@@ -15,8 +15,8 @@
     join  also applies the queue update core.clj:52-58 asks for next (now when complete, else the nearer of the
           current date and now + max-wait).
   The calls core.clj then makes (store-in-publish-queue, store-nearest-in-publish-queue) find the state they
-  would have produced and leave it as it is.  :count of join's answer is what all-there? (core.clj:36-38) needs:
-  the metadata's :count when every position has arrived, -1 otherwise (the engine does not report HLEN).
+  would have produced and leave it as it is.  :count of join's answer is HLEN of the barrier's hash after the event
+  (redis.clj:137,157), which the engine reports in the event's status word (dj_set_join_hlen).
 
   Id strings and the Fork maps (URLs) stay in this JVM, keyed by fingerprint; counts, deadlines, retry counters,
   messages and both queues live in HBM."
@@ -75,13 +75,18 @@
 
 (declare join-metadata)
 
+;; redis/join answers HLEN (redis.clj:137,157): the engine puts it into every join's status word from here on
+(defonce ^:private hlen-on
+  (delay (es/check (es/native-int es/dj "dj_set_join_hlen" @es/engine (int 1)) "dj_set_join_hlen")))
+
 ;; redis.clj:143-159
 (defn join [record]
-  (deferred/let-flow [status (es/join-status record)
-                      failure (es/join-failure status)                   ; an error deferred stops the flow here
+  @hlen-on
+  (deferred/let-flow [word (es/join-word record)
+                      failure (es/join-failure (bit-and (int word) 0xFF))   ; an error deferred stops the flow here
                       metadata (join-metadata (:barrier-id record))]
     {:metadata metadata
-     :count    (if (= 2 (int status)) (:count metadata) -1)}))           ; DJ_JOIN_COMPLETE
+     :count    (unsigned-bit-shift-right (bit-and (long word) 0xFFFFFFFF) 8)}))   ; DJ_JOIN_HLEN: HLEN after this HSET
 
 ;; redis.clj:191-205
 (defn complete [barrier-id]

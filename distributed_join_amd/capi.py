@@ -27,6 +27,17 @@ DJ_ACK_DIRTY, DJ_ACK_METADATA_SET = 6, 7
 DJ_CONT_TIMEOUT, DJ_CONT_NO_METADATA = 1, 2
 DJ_CONT_VOID = CONT_VOID = 0x80000000
 DJ_STATIC_JOIN_MAX = 65536
+DJ_JOIN_HLEN_SHIFT = 8
+
+
+def join_status(word):
+    """DJ_JOIN_STATUS: the answer code of a join status word."""
+    return int(word) & 0xFF
+
+
+def join_hlen(word):
+    """DJ_JOIN_HLEN: HLEN of the barrier's hash after the event (engines with set_join_hlen(True))."""
+    return (int(word) & 0xFFFFFFFF) >> DJ_JOIN_HLEN_SHIFT
 
 # ---- record layouts (little-endian, no padding surprises: all fields naturally aligned)
 FORK_REC = np.dtype([("fp_lo", "<u8"), ("fp_hi", "<u8"), ("count", "<u4"), ("reserved", "<u4"),
@@ -62,7 +73,8 @@ SYMBOLS = ["dj_create", "dj_destroy", "dj_last_error", "dj_sync", "dj_stream", "
            "dj_get_config", "dj_fetch_long", "dj_join_batch_static",
            "dj_set_sweep_path", "dj_route_plan", "dj_route_unique_id", "dj_router_create", "dj_router_destroy",
            "dj_router_last_error", "dj_route_start", "dj_route_advance", "dj_route_next", "dj_route_release",
-           "dj_complete_one", "dj_update_metadata_one", "dj_store_nearest_in_publish_queue", "dj_unprocessed"]
+           "dj_complete_one", "dj_update_metadata_one", "dj_store_nearest_in_publish_queue", "dj_unprocessed",
+           "dj_set_join_hlen", "dj_scatter_statuses", "dj_route_status_buffer", "dj_route_return", "dj_route_statuses"]
 # include/dj_batcher.h
 BATCHER_SYMBOLS = ["dj_batcher_create", "dj_batcher_destroy", "dj_batcher_set_clock", "dj_batcher_join",
                    "dj_batcher_fork", "dj_batcher_join_wait", "dj_batcher_fork_wait", "dj_batcher_run",
@@ -158,6 +170,9 @@ def load():
     if not os.environ.get("DJ_ENGINE_LIB") or hasattr(L, "dj_set_sweep_path"):     # an older build under A/B lacks it
         L.dj_set_sweep_path.restype = i32
         L.dj_set_sweep_path.argtypes = [vp, i32]
+    if not os.environ.get("DJ_ENGINE_LIB") or hasattr(L, "dj_set_join_hlen"):
+        L.dj_set_join_hlen.restype = i32
+        L.dj_set_join_hlen.argtypes = [vp, i32]
     L.dj_checkpoint_save.restype = i32
     L.dj_checkpoint_save.argtypes = [vp, ctypes.c_char_p]
     L.dj_checkpoint_load.restype = i32
@@ -186,6 +201,15 @@ def load():
                                     ctypes.POINTER(ctypes.c_int)]
         L.dj_route_release.restype = i32
         L.dj_route_release.argtypes = [vp, ctypes.c_int]
+    if not os.environ.get("DJ_ENGINE_LIB") or hasattr(L, "dj_route_return"):
+        L.dj_scatter_statuses.restype = i32
+        L.dj_scatter_statuses.argtypes = [vp, u32, vp, vp, vp, vp]
+        L.dj_route_status_buffer.restype = i32
+        L.dj_route_status_buffer.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp)]
+        L.dj_route_return.restype = i32
+        L.dj_route_return.argtypes = [vp, ctypes.c_int]
+        L.dj_route_statuses.restype = i32
+        L.dj_route_statuses.argtypes = [vp, ctypes.c_int, vp, vp]
     L.dj_batcher_create.restype = i32
     L.dj_batcher_create.argtypes = [vp, ctypes.POINTER(BatcherConfig), ctypes.POINTER(vp)]
     L.dj_batcher_destroy.restype = None

@@ -192,6 +192,8 @@ struct Work {
     uint32_t* cx_nq;              // [CX_CAP] 1 when the barrier was not in the primary queue before the batch
     uint32_t cx_on;               // 1: this batch runs the parallel hot-barrier kernels
     uint32_t publish_hints;       // 1: the link pass hands the previous batch's counters (the other bank) to the host
+    uint32_t hlen;                // 1: every accepted event's status word also carries HLEN of its barrier's hash right
+                                  // after the event, above DJ_JOIN_HLEN_SHIFT (dj_set_join_hlen)
     uint32_t fused;               // 1: the link pass has copied every accepted event's message into its row already; the
                                   // resolve passes copy again where a later event of the batch wrote the same position
     // bucketed join path (join_link_bucket_kernel / join_resolve_bucket_kernel)

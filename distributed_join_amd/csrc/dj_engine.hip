@@ -63,6 +63,7 @@ struct dj_engine {
     uint32_t n_cus;              // compute units of the device
     int bucket_mode;             // -1: the bucketed join passes where they pay; 0: never; 1: wherever they apply (tests)
     int fuse_off;                // 1: the link pass never copies messages itself (dj_set_hot_path mode + 4: tests of the separate copy pass)
+    int hlen_mode;               // 1: join statuses carry HLEN above DJ_JOIN_HLEN_SHIFT (dj_set_join_hlen)
     int cx_force;                // -1: automatic; else bit 0: parallel hot-barrier kernels, bit 1: wide register replay (tests)
     unsigned int* h_maxchain;    // pinned: longest chain of the previous join batch (picks the hot-barrier kernels)
     uint64_t used_upper;         // upper bound of non-empty slots (live + tombstones) since the last compaction
@@ -371,6 +372,7 @@ extern "C" int dj_create(const dj_config* cfg, dj_engine** out) {
     e->h_maxchain = nullptr;
     e->compact_ev = nullptr;
     e->cx_force = -1;
+    e->hlen_mode = 0;
     e->fuse_off = 0;
     e->bucket_mode = -1;
     {
@@ -421,6 +423,13 @@ extern "C" int dj_set_hot_path(dj_engine* e, int mode) {
     e->fuse_off = mode >= 4 ? 1 : 0;
     if (mode >= 4) mode -= 4;
     e->cx_force = only_bucket ? -1 : mode;
+    return DJ_OK;
+}
+
+extern "C" int dj_set_join_hlen(dj_engine* e, int on) {
+    if (!e || on < 0 || on > 1) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
+    e->hlen_mode = on;
     return DJ_OK;
 }
 
@@ -599,6 +608,8 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
     // look like (measured: 100 barriers x 250 events and 500 x 200 break even, 8192 x 128 and anything longer
     // than the serial kernel's 256-entry chain copy go parallel, 2000 x 50 and 8000 x 12 stay serial).
     const unsigned int rounds = hint[0] / 2048 + 1;
+    w.hlen = e->hlen_mode ? 1u : 0u;
+    if (w.hlen) serial_only = true;      // HLEN after every single event: only the replays that go event by event have it
     w.cx_on = serial_only ? 0u : e->cx_force >= 0 ? (uint32_t)(e->cx_force & 1) : ((uint64_t)rounds * hint[1] > 256 ? 1u : 0u);
     // Fused form: the link pass copies every accepted event's message into its row itself (one pass less over the
     // events, and the copy's streaming overlaps the link's atomics); the resolve passes copy a position again where
@@ -1285,6 +1296,20 @@ extern "C" int dj_partition_joins(dj_engine* e, uint32_t n, uint32_t n_ranks, co
     else if (lanes <= 32) DJ_SCATTER(32);
     else DJ_SCATTER(64);
 #undef DJ_SCATTER
+    HIP_TRY(e, hipGetLastError());
+    return DJ_OK;
+}
+
+extern "C" int dj_scatter_statuses(dj_engine* e, uint32_t n, const uint32_t* d_origin, const int32_t* d_sorted, int32_t* d_out, void* stream) {
+    if (!e) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
+    if (n == 0) return DJ_OK;
+    if (!d_origin || !d_sorted || !d_out) return fail(e, DJ_E_INVALID, "scatter_statuses: null pointer");
+    if (n > e->cfg.max_batch) return fail(e, DJ_E_TOO_LARGE, "scatter_statuses: n=%u exceeds max_batch=%u", n, e->cfg.max_batch);
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    uint32_t blocks = grid_for(n, 256);
+    if (blocks > 2048) blocks = 2048;
+    scatter_statuses_kernel<<<blocks, 256, 0, stream ? (hipStream_t)stream : e->stream>>>(n, d_origin, d_sorted, d_out);
     HIP_TRY(e, hipGetLastError());
     return DJ_OK;
 }

@@ -316,7 +316,7 @@ join_link_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t 
     }
     if constexpr (G > 0) wave_copy_rows<G>(t, payloads, pitch, (uint64_t)i - (threadIdx.x & 63), row_off, row_len);
     // a sample for the host: how ragged is the traffic (it decides how the next barriers are forked)
-    if (blockIdx.x == 0 && threadIdx.x < 256) {
+    if (blockIdx.x == 0 && threadIdx.x < 256 && w.publish_hints) {
         const uint64_t m = __ballot(stores_meta);
         if ((threadIdx.x & 63) == 0) w.hint[4 + (threadIdx.x >> 6)] = (unsigned int)__popcll(m);
     }
@@ -410,7 +410,8 @@ __device__ __forceinline__ bool replay_short_chain(const Table& t, const Work& w
                 done |= 1u << bk;
                 const uint32_t pos = node_pos(bn);
                 const int32_t st = replay_one(t, s, slab, r, pos, node_mw(bn), now);
-                if (st != DJ_JOIN_WAITING) status[best] = st;
+                if (w.hlen) status[best] = st | (int32_t)(r.arrived << DJ_JOIN_HLEN_SHIFT);     // HLEN after this event's HSET (redis.clj:135-137)
+                else if (st != DJ_JOIN_WAITING) status[best] = st;
                 bool last = true;   // last writer of its position inside the batch: no later event has it
 #pragma unroll
                 for (int k = 0; k < CR; ++k)
@@ -592,7 +593,7 @@ join_link_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, ui
         }
         wave_copy_rows<G>(t, payloads, pitch, (uint64_t)i - lane, row_off, row_len);
         // a sample for the host: how ragged is the traffic (the batch's first 4 x 64 events)
-        if (blockIdx.x == 0 && k == 0 && wave < 4) {
+        if (blockIdx.x == 0 && k == 0 && wave < 4 && w.publish_hints) {
             const uint64_t m = __ballot(stores_meta);
             if (lane == 0) w.hint[4 + wave] = (unsigned int)__popcll(m);
         }
@@ -858,10 +859,12 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
             }
             __syncthreads();
         }
-        if (meta0 & META_KX_MASK) {
+        const bool one_by_one = (meta0 & META_KX_MASK) != 0 || w.hlen != 0;
+        if (one_by_one) {
             // The barrier holds messages beyond its count (a failed publish wrote an older, smaller count back): HLEN
             // can pass the count and come back, so there is no single first COMPLETE index.  Lane 0 replays the events
-            // one by one in array order, as core/join would (core.clj:44-58).
+            // one by one in array order, as core/join would (core.clj:44-58).  The same replay serves callers that want
+            // HLEN with every answer: it is the one form that has the hash's size after each single event.
             const uint32_t len = s_len;
             if (!scan && len <= CHAIN_LDS) {
                 // order of the chain's entries by event index: entry k has as many entries before it as are smaller
@@ -894,7 +897,8 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
                     if (pa == NQ) st = DJ_JOIN_NEAREST_NOT_QUEUED;
                     else if (pa > now + 1000ull * mw) { pa = now + 1000ull * mw; dirty = true; }
                 }
-                if (st != DJ_JOIN_WAITING) status[i] = st;
+                if (w.hlen) status[i] = st | (int32_t)(arrived << DJ_JOIN_HLEN_SHIFT);
+                else if (st != DJ_JOIN_WAITING) status[i] = st;
                 if (!w.fused && fmax[pos] != i + 1) w.dst[i] = NODST;
             };
             if (!scan && len <= CHAIN_LDS) {
@@ -921,7 +925,7 @@ __global__ void __launch_bounds__(64) join_resolve_complex_kernel(Table t, Work 
                 else if (dirty) { t.q[s] = pa; note_queue_date(t, s, pa); }
             }
         }
-        const bool plain = !(meta0 & META_KX_MASK);
+        const bool plain = !one_by_one;
         // newly present positions: 64 positions (one bitmap word) per step, one lane per position
         uint32_t t_complete = 0, n_new = 0;
         const uint32_t words = plain ? (count + 63) >> 6 : 0;          // (the replay above has done all of this otherwise)
@@ -1520,9 +1524,15 @@ __global__ void __launch_bounds__(256) pop_ready_kernel(Table t, Work w, uint64_
                 has = a_cas(&t.q[s], pa, pa | Q_POPPED);       // false: another entry of the same slot got it
             } else {
                 has = false;
-                // queued for later (a re-fork, or a caller whose clock went back): the bound must cover it
-                if (!(pa >> 63) && pa < a_load(w.due_next))
-                    __hip_atomic_fetch_min(w.due_next, (unsigned long long)pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // queued for later (a re-fork, or a caller whose clock went back): the list is emptied after this sweep,
+                // so both bounds must cover the date from here on (a completion writes its date to the list only, and
+                // its region's bound may still be the fork's deadline)
+                if (!(pa >> 63)) {
+                    if (pa < a_load(w.due_next))
+                        __hip_atomic_fetch_min(w.due_next, (unsigned long long)pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned long long* rb = &t.qmin[s >> REGION_SHIFT];
+                    if (pa < a_load(rb)) __hip_atomic_fetch_min(rb, (unsigned long long)pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
         pop_emit_round(t, w, sh, has, s, pa, true, now, cap_conts, cap_pos, alloc_pos, conts);
@@ -2364,6 +2374,13 @@ __global__ void __launch_bounds__(PART_BLOCK) partition_scatter_kernel(const dj_
             }
         }
     }
+}
+
+// The way back of a routed batch: sorted[j] answers the record that dj_partition_joins moved from place origin[j] of
+// the caller's batch to place j: out[origin[j]] = sorted[j].  Reads stream, the 4-byte stores scatter.
+__global__ void __launch_bounds__(256) scatter_statuses_kernel(uint32_t n, const uint32_t* origin, const int32_t* sorted, int32_t* out) {
+    for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x)
+        out[origin[j]] = sorted[j];
 }
 
 }  // namespace dj

@@ -112,13 +112,25 @@ struct Set {
     uint32_t* origin = nullptr;
     uint32_t* counts = nullptr;       // [world] this rank's bucket sizes (device)
     uint32_t* matrix_d = nullptr;     // [world * world] everybody's
-    uint32_t* matrix_h = nullptr;     // pinned copy
+    uint32_t* gathered_h = nullptr;   // pinned copy of matrix_d: per rank its world bucket sizes and one word "has messages"
+    uint32_t* matrix_h = nullptr;     // the world x world bucket sizes alone, as dj_route_plan reads them
     dj_join_rec* recv_recs = nullptr;
     uint8_t* recv_pay = nullptr;
+    // the way back: the engine writes a piece's statuses to status_piece (piece order), they return to the ranks
+    // their records came from and land in ret_sorted at the place of their record in recs_sorted
+    int32_t* status_piece = nullptr;  // [max_recv]
+    int32_t* ret_sorted = nullptr;    // [max_send]
     hipEvent_t parted = nullptr, counts_ev = nullptr, ready = nullptr, freed = nullptr;
+    hipEvent_t applied = nullptr;     // engine stream: the call that wrote status_piece has been queued
+    hipEvent_t returned = nullptr;    // communication stream: the latest piece's statuses have left status_piece
+    hipEvent_t home = nullptr;        // communication stream: dj_route_statuses' scatter is done
     bool free_pending = false, has_pay = false, active = false, planned = false;
+    bool unplanned_release = false;   // the set was released before its bucket sizes were ever waited for
+    bool return_pending = false;      // `returned` has been recorded and nobody has waited for it yet
+    bool home_pending = false;        // `home` likewise: the next partition into this set must not overwrite origin[] before
     uint32_t n = 0, rounds = 0;
     uint32_t round = 0;               // pieces handed to the caller
+    uint32_t returned_rounds = 0;     // pieces whose statuses have been sent back
     uint32_t issued = 0;              // pieces whose exchange has been queued (round or round + 1)
     uint32_t n_in = 0;                // rows of the piece queued last
     uint32_t bucket_off[MAX_RANKS];   // where each destination's bucket starts in recs_sorted
@@ -184,7 +196,12 @@ extern "C" void dj_router_destroy(dj_router* r) {
         Set& s = r->sets[k];
         (void)hipFree(s.recs_sorted); (void)hipFree(s.pay_sorted); (void)hipFree(s.origin); (void)hipFree(s.counts);
         (void)hipFree(s.matrix_d); (void)hipFree(s.recv_recs); (void)hipFree(s.recv_pay);
+        (void)hipFree(s.status_piece); (void)hipFree(s.ret_sorted);
+        if (s.applied) (void)hipEventDestroy(s.applied);
+        if (s.returned) (void)hipEventDestroy(s.returned);
+        if (s.home) (void)hipEventDestroy(s.home);
         if (s.matrix_h) (void)hipHostFree(s.matrix_h);
+        if (s.gathered_h) (void)hipHostFree(s.gathered_h);
         if (s.parted) (void)hipEventDestroy(s.parted);
         if (s.counts_ev) (void)hipEventDestroy(s.counts_ev);
         if (s.ready) (void)hipEventDestroy(s.ready);
@@ -221,11 +238,17 @@ extern "C" int dj_router_create(dj_engine* e, uint32_t n_ranks, uint32_t rank, c
             R_HIP(nullptr, hipMalloc((void**)&s.recs_sorted, (size_t)max_send * 32));
             R_HIP(nullptr, hipMalloc((void**)&s.pay_sorted, (size_t)max_send * pitch));
             R_HIP(nullptr, hipMalloc((void**)&s.origin, (size_t)max_send * 4));
-            R_HIP(nullptr, hipMalloc((void**)&s.counts, MAX_RANKS * 4));
-            R_HIP(nullptr, hipMalloc((void**)&s.matrix_d, (size_t)MAX_RANKS * MAX_RANKS * 4));
+            R_HIP(nullptr, hipMalloc((void**)&s.counts, (MAX_RANKS + 1) * 4));
+            R_HIP(nullptr, hipMalloc((void**)&s.matrix_d, (size_t)MAX_RANKS * (MAX_RANKS + 1) * 4));
+            R_HIP(nullptr, hipHostMalloc((void**)&s.gathered_h, (size_t)MAX_RANKS * (MAX_RANKS + 1) * 4, hipHostMallocDefault));
             R_HIP(nullptr, hipHostMalloc((void**)&s.matrix_h, (size_t)MAX_RANKS * MAX_RANKS * 4, hipHostMallocDefault));
             R_HIP(nullptr, hipMalloc((void**)&s.recv_recs, (size_t)max_recv * 32));
             R_HIP(nullptr, hipMalloc((void**)&s.recv_pay, (size_t)max_recv * pitch));
+            R_HIP(nullptr, hipMalloc((void**)&s.status_piece, (size_t)max_recv * 4));
+            R_HIP(nullptr, hipMalloc((void**)&s.ret_sorted, (size_t)max_send * 4));
+            R_HIP(nullptr, hipEventCreateWithFlags(&s.applied, hipEventDisableTiming));
+            R_HIP(nullptr, hipEventCreateWithFlags(&s.returned, hipEventDisableTiming));
+            R_HIP(nullptr, hipEventCreateWithFlags(&s.home, hipEventDisableTiming));
             R_HIP(nullptr, hipEventCreateWithFlags(&s.parted, hipEventDisableTiming));
             R_HIP(nullptr, hipEventCreateWithFlags(&s.counts_ev, hipEventDisableTiming));
             R_HIP(nullptr, hipEventCreateWithFlags(&s.ready, hipEventDisableTiming));
@@ -257,18 +280,30 @@ extern "C" int dj_route_start(dj_router* r, uint32_t n, const dj_join_rec* d_rec
         R_HIP(r, hipStreamWaitEvent(r->stream, s.freed, 0));
         s.free_pending = false;
     }
+    if (s.home_pending) {                 // the scatter of the set's previous batch may still be reading origin[]
+        R_HIP(r, hipStreamWaitEvent(r->stream, s.home, 0));
+        s.home_pending = false;
+    }
+    if (s.unplanned_release) {            // released without a piece taken: its all-gather may still be reading counts[]
+        R_HIP(r, hipStreamWaitEvent(r->stream, s.counts_ev, 0));
+        s.unplanned_release = false;
+    }
     s.has_pay = d_payloads != nullptr;
     s.n = n;
     s.planned = false;
-    s.round = s.rounds = s.issued = s.n_in = 0;
+    s.return_pending = false;
+    s.round = s.rounds = s.issued = s.n_in = s.returned_rounds = 0;
     int rc = dj_partition_joins(r->e, n, (uint32_t)r->world, d_recs, d_payloads, r->pitch, s.recs_sorted,
                                 s.has_pay ? s.pay_sorted : nullptr, s.origin, s.counts, r->stream);
     if (rc != DJ_OK) return rfail(r, rc, "route: partition failed: %s", dj_last_error(r->e));
+    // one more word behind the bucket sizes: does this rank's batch come with messages?  Every rank must agree (the
+    // exchange pairs a send with a receive), and with the word in the gathered matrix every rank can check that
+    R_HIP(r, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(s.counts + r->world), s.has_pay ? 1 : 0, 1, r->stream));
     R_HIP(r, hipEventRecord(s.parted, r->stream));
     R_HIP(r, hipStreamWaitEvent(r->comm_stream, s.parted, 0));
-    // everybody's bucket sizes to everybody (world * world words), then to this host without waiting
-    R_NCCL(r, g_rccl.AllGather(s.counts, s.matrix_d, (size_t)r->world, ncclUint32, r->comm, r->comm_stream));
-    R_HIP(r, hipMemcpyAsync(s.matrix_h, s.matrix_d, (size_t)r->world * r->world * 4, hipMemcpyDeviceToHost, r->comm_stream));
+    // everybody's bucket sizes to everybody (world * (world + 1) words), then to this host without waiting
+    R_NCCL(r, g_rccl.AllGather(s.counts, s.matrix_d, (size_t)r->world + 1, ncclUint32, r->comm, r->comm_stream));
+    R_HIP(r, hipMemcpyAsync(s.gathered_h, s.matrix_d, (size_t)r->world * (r->world + 1) * 4, hipMemcpyDeviceToHost, r->comm_stream));
     R_HIP(r, hipEventRecord(s.counts_ev, r->comm_stream));
     s.active = true;
     *handle = r->turn;
@@ -282,6 +317,13 @@ static int issue_piece(dj_router* r, Set& s) {
     const uint32_t w = (uint32_t)r->world;
     if (!s.planned) {
         R_HIP(r, hipEventSynchronize(s.counts_ev));      // already there when the start was issued a batch ahead
+        for (uint32_t q = 0; q < w; ++q) {
+            memcpy(s.matrix_h + (size_t)q * w, s.gathered_h + (size_t)q * (w + 1), (size_t)w * 4);
+            // the same verdict on every rank (they all read the same matrix), before any rank has queued a transfer
+            if ((s.gathered_h[(size_t)q * (w + 1) + w] != 0) != s.has_pay)
+                return rfail(r, DJ_E_INVALID, "route: rank %u started this batch %s messages, rank %d %s them", q,
+                             s.has_pay ? "without" : "with", r->rank, s.has_pay ? "with" : "without");
+        }
         uint32_t off = 0;
         for (uint32_t p = 0; p < w; ++p) { s.bucket_off[p] = off; off += s.matrix_h[(size_t)r->rank * w + p]; }
         s.rounds = dj_route_plan(w, (uint32_t)r->rank, s.matrix_h, r->max_recv, 0, nullptr, nullptr, nullptr);
@@ -351,6 +393,10 @@ extern "C" int dj_route_next(dj_router* r, int handle, const dj_join_rec** d_rec
         if (rc != DJ_OK) return rc;
     }
     R_HIP(r, hipStreamWaitEvent(r->engine_stream, s.ready, 0));      // the engine's stream waits, the host does not
+    if (s.return_pending) {                // the previous piece's statuses must have left status_piece
+        R_HIP(r, hipStreamWaitEvent(r->engine_stream, s.returned, 0));
+        s.return_pending = false;
+    }
     ++s.round;
     *d_recs_out = s.recv_recs;
     if (d_payloads_out) *d_payloads_out = s.has_pay ? s.recv_pay : nullptr;
@@ -368,6 +414,77 @@ extern "C" int dj_route_release(dj_router* r, int handle) {
     R_HIP(r, hipSetDevice(r->cfg.device));
     R_HIP(r, hipEventRecord(s.freed, r->engine_stream));
     s.free_pending = true;
+    s.unplanned_release = !s.planned;
     s.active = false;
+    return DJ_OK;
+}
+
+// ---- the way back: per-record answers to the rank that submitted the record ----------------------------------------
+extern "C" int dj_route_status_buffer(dj_router* r, int handle, int32_t** d_status_piece) {
+    if (!r || handle < 0 || handle >= r->depth || !d_status_piece) return DJ_E_INVALID;
+    std::lock_guard<std::mutex> g(r->mu);
+    Set& s = r->sets[handle];
+    if (!s.active) return rfail(r, DJ_E_INVALID, "route: handle %d is not in flight", handle);
+    *d_status_piece = s.status_piece;
+    return DJ_OK;
+}
+
+extern "C" int dj_route_return(dj_router* r, int handle) {
+    if (!r || handle < 0 || handle >= r->depth) return DJ_E_INVALID;
+    std::lock_guard<std::mutex> g(r->mu);
+    Set& s = r->sets[handle];
+    if (!s.active || !s.planned || s.round == 0) return rfail(r, DJ_E_INVALID, "route: handle %d has no piece whose statuses could return", handle);
+    if (s.returned_rounds + 1 != s.round) return rfail(r, DJ_E_INVALID, "route: the statuses of piece %u of handle %d have %s", s.round - 1, handle,
+                                                        s.returned_rounds == s.round ? "been returned already" : "to follow those of the piece before it");
+    R_HIP(r, hipSetDevice(r->cfg.device));
+    const uint32_t w = (uint32_t)r->world;
+    // the piece's plan once more, read backwards: what this rank received from p it answers to p, what it sent to p it
+    // gets answers for, at the same places
+    uint32_t send_off[MAX_RANKS], send_cnt[MAX_RANKS], recv_cnt[MAX_RANKS], at[MAX_RANKS];
+    dj_route_plan(w, (uint32_t)r->rank, s.matrix_h, r->max_recv, s.round - 1, send_off, send_cnt, recv_cnt);
+    uint32_t n_in = 0;
+    for (uint32_t p = 0; p < w; ++p) { at[p] = n_in; n_in += recv_cnt[p]; }
+    // behind the engine call that writes the statuses (the caller has queued it), on the communication stream
+    R_HIP(r, hipEventRecord(s.applied, r->engine_stream));
+    R_HIP(r, hipStreamWaitEvent(r->comm_stream, s.applied, 0));
+    R_NCCL(r, g_rccl.GroupStart());
+    auto queue_transfers = [&]() -> int {
+        for (uint32_t p = 0; p < w; ++p) {
+            const int32_t* from = s.status_piece + at[p];
+            int32_t* to = s.ret_sorted + s.bucket_off[p] + send_off[p];
+            if ((int)p == r->rank) {
+                if (send_cnt[p]) R_HIP(r, hipMemcpyAsync(to, from, (size_t)send_cnt[p] * 4, hipMemcpyDeviceToDevice, r->comm_stream));
+                continue;
+            }
+            if (recv_cnt[p]) R_NCCL(r, g_rccl.Send(from, (size_t)recv_cnt[p], ncclInt32, (int)p, r->comm, r->comm_stream));
+            if (send_cnt[p]) R_NCCL(r, g_rccl.Recv(to, (size_t)send_cnt[p], ncclInt32, (int)p, r->comm, r->comm_stream));
+        }
+        return DJ_OK;
+    };
+    const int queued = queue_transfers();
+    const ncclResult_t ended = g_rccl.GroupEnd();
+    if (queued != DJ_OK) return queued;
+    R_NCCL(r, ended);
+    R_HIP(r, hipEventRecord(s.returned, r->comm_stream));
+    s.return_pending = true;
+    ++s.returned_rounds;
+    return DJ_OK;
+}
+
+extern "C" int dj_route_statuses(dj_router* r, int handle, int32_t* d_status_out, void* stream) {
+    if (!r || handle < 0 || handle >= r->depth) return DJ_E_INVALID;
+    std::lock_guard<std::mutex> g(r->mu);
+    Set& s = r->sets[handle];
+    if (!s.active || !s.planned) return rfail(r, DJ_E_INVALID, "route: handle %d is not in flight", handle);
+    if (s.returned_rounds != s.rounds) return rfail(r, DJ_E_INVALID, "route: %u of the %u pieces of handle %d have returned their statuses", s.returned_rounds, s.rounds, handle);
+    if (s.n && !d_status_out) return rfail(r, DJ_E_INVALID, "route: null status buffer");
+    R_HIP(r, hipSetDevice(r->cfg.device));
+    // ret_sorted[j] answers record j of recs_sorted, which was record origin[j] of the caller's batch
+    const int rc = dj_scatter_statuses(r->e, s.n, s.origin, s.ret_sorted, d_status_out, r->comm_stream);
+    if (rc != DJ_OK) return rfail(r, rc, "route: scatter failed: %s", dj_last_error(r->e));
+    R_HIP(r, hipEventRecord(s.home, r->comm_stream));
+    s.home_pending = true;
+    if (stream) R_HIP(r, hipStreamWaitEvent((hipStream_t)stream, s.home, 0));
+    else R_HIP(r, hipEventSynchronize(s.home));
     return DJ_OK;
 }

@@ -321,6 +321,10 @@ class Engine:
         batches fill (same results)."""
         self._check(self.L.dj_set_sweep_path(self.h, int(mode)))
 
+    def set_join_hlen(self, on=True):
+        """Join status words also carry HLEN (redis/join's :count, redis.clj:137,157): capi.join_status / capi.join_hlen."""
+        self._check(self.L.dj_set_join_hlen(self.h, 1 if on else 0))
+
     def checkpoint_save(self, path):
         """Write the whole barrier state to a file (waits for the stream)."""
         self._check(self.L.dj_checkpoint_save(self.h, str(path).encode()))

@@ -13,8 +13,8 @@ between two commands made on the device.  This one is the reference's own granul
     fork                 :90-104        dj_fork_batch (one record; it also queues the barrier at :timeout-secs,
                                         which core.clj:30 asks for in its next call)
     update-metadata      :106-111       dj_update_metadata_one
-    join                 :143-159       dj_join_batch (one event; the queue update core.clj:52-58 asks for next
-                                        is already applied)
+    join                 :143-159       dj_join_batch (one event, with dj_set_join_hlen: the status word carries HLEN;
+                                        the queue update core.clj:52-58 asks for next is already applied)
     complete             :191-205       dj_complete_one
     all-joins            :242-243       dj_snapshot_one, update_ts = 1
     all-joins-status     :245-246       dj_snapshot_one, update_ts = 0
@@ -58,6 +58,7 @@ def make_key(join_id, transaction_id):
 class EngineRedis:
     def __init__(self, engine, clock, env):
         self.e = engine
+        self.e.set_join_hlen(True)      # redis/join answers HLEN (redis.clj:157): the status words carry it
         self.clock = clock              # time-util/now-milliseconds, time_util.clj:3-4
         self.env = env
         # the host half of "<id>:metadata": the strings of the Fork map (ids, URLs).  Count, :timeout-secs and
@@ -115,7 +116,8 @@ class EngineRedis:
         pay = np.zeros((1, pitch), dtype=np.uint8)
         if len(msg) <= pitch:
             pay[0, :len(msg)] = np.frombuffer(msg, dtype=np.uint8)
-        st = int(self.e.join_batch(rec, pay, self.clock())[0])
+        word = int(self.e.join_batch(rec, pay, self.clock())[0])
+        st, hlen = capi.join_status(word), capi.join_hlen(word)
         if st == capi.DJ_JOIN_NOT_FOUND:
             raise err("not-found", "barrier-id does not exist")               # redis.clj:152,159
         if st == capi.DJ_JOIN_BAD_POSITION:
@@ -124,10 +126,8 @@ class EngineRedis:
             raise err("bad-data", f"Message length cannot exceed {self.env['join-message-len-max']}")
         if st not in (capi.DJ_JOIN_WAITING, capi.DJ_JOIN_COMPLETE, capi.DJ_JOIN_NEAREST_NOT_QUEUED):
             raise database_failure(f"join status {st}")
-        md = self.join_metadata(bid)
-        # :count is HLEN.  The engine answers what core.clj derives from it (all-there?, core.clj:36-38): the
-        # metadata's count when every position has arrived, -1 ("not all") otherwise.
-        return {"metadata": md, "count": md["count"] if st == capi.DJ_JOIN_COMPLETE and md else -1}
+        # :count is HLEN of the hash after this HSET (redis.clj:137,157), whatever the metadata's :count says
+        return {"metadata": self.join_metadata(bid), "count": hlen}
 
     # redis.clj:191-205
     def complete(self, barrier_id):

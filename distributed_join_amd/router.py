@@ -28,6 +28,10 @@ sizes only when the rows are exchanged (advance() / finish()), one batch later.
         recs_in, pay_in, n_in = router.next_round(h)
         engine.join_batch_dev(n_in, recs_in, pay_in, ...)
     router.release(h)                         # after the batch's kernels are queued: buffers may be reused
+Per-record answers (what the reference's handlers send back, ring.clj:54-69) return to the submitting rank:
+    engine.join_batch_dev(n_in, recs_in, pay_in, ..., router.status_buffer(h))    # per piece
+    router.return_statuses(h)                 # per piece, a collective: 4 bytes per record over the plan read backwards
+    router.statuses(h, d_status_out, stream)  # once, before release: this rank's n answers in its submission order
 """
 import os
 import sys
@@ -84,6 +88,25 @@ def exchange_round(dist, group, rank, matrix, max_recv, rnd, recs_sorted, pay_so
     return n_in, rounds
 
 
+def return_round(dist, group, rank, matrix, max_recv, rnd, status_piece, ret_sorted):
+    """The way back of round `rnd`: status_piece[:n_in] holds one answer per row this rank received in that round
+    (piece order); every answer goes to the rank its row came from and lands in ret_sorted at the place the row has
+    in that rank's recs_sorted.  The same plan as exchange_round, read backwards: one all_to_all_single."""
+    import torch
+    _, send_off, send_cnt, recv_cnt = capi.route_plan(matrix, rank, max_recv, rnd)
+    bucket = [int(x) for x in matrix[rank]]
+    starts = np.concatenate([[0], np.cumsum(bucket)[:-1]]).tolist()
+    n_in, n_out = sum(recv_cnt), sum(send_cnt)
+    whole = all(o == 0 and c == b for o, c, b in zip(send_off, send_cnt, bucket))
+    back = ret_sorted[:n_out] if whole else torch.empty(n_out, dtype=ret_sorted.dtype, device=ret_sorted.device)
+    dist.all_to_all_single(back, status_piece[:n_in], output_split_sizes=send_cnt, input_split_sizes=recv_cnt, group=group)
+    if not whole:
+        at = 0
+        for st, o, c in zip(starts, send_off, send_cnt):
+            ret_sorted[st + o:st + o + c] = back[at:at + c]
+            at += c
+
+
 def exchange(dist, group, recs_sorted, pay_sorted, send_counts, recv_recs, recv_pay):
     """all-to-all-v of records (rows of recs_sorted, grouped by destination rank) and messages (rows of
     pay_sorted, optional) in as many rounds as the receive buffers need; the pieces are handed to `yield`-free
@@ -111,6 +134,14 @@ class _Slot:
         self.matrix_h = torch.empty(world * world, dtype=torch.int32).pin_memory()
         self.recv_recs = torch.empty((max_recv, 4), dtype=torch.int64, device=dev)
         self.recv_pay = torch.empty((max_recv, pitch), dtype=torch.uint8, device=dev)
+        self.status_piece = torch.empty(max_recv, dtype=torch.int32, device=dev)    # the engine's answers to the current piece
+        self.ret_sorted = torch.empty(max_send, dtype=torch.int32, device=dev)      # answers to this rank's own records, bucket order
+        self.returned = torch.cuda.Event()   # the latest piece's answers have left status_piece (router's stream)
+        self.home = torch.cuda.Event()       # statuses(): the answers are in the caller's order
+        self.return_pending = False
+        self.home_pending = False
+        self.returned_rounds = 0
+        self.n = 0
         self.parted = torch.cuda.Event()     # the partition is done (recorded on the partition stream)
         self.sizes_in = torch.cuda.Event()   # the bucket sizes are in host memory
         self.ready = torch.cuda.Event()      # data has arrived (recorded on the router's stream)
@@ -156,8 +187,12 @@ class Router:
             if s.free_pending:                    # the engine may still be reading this buffer set
                 self.stream.wait_event(s.free)
                 s.free_pending = False
+            if s.home_pending:                    # the scatter of this set's previous batch reads origin[]
+                self.stream.wait_event(s.home)
+                s.home_pending = False
             s.has_pay = d_payloads is not None
             s.matrix, s.round, s.rounds, s.host = None, 0, 0, None
+            s.n, s.returned_rounds, s.return_pending = int(n), 0, False
             self.e.partition_joins_dev(n, self.world, d_recs, d_payloads, self.pitch, s.recs_sorted,
                                        s.pay_sorted if s.has_pay else None, s.origin, s.counts,
                                        stream_ptr=self.stream.cuda_stream)
@@ -211,6 +246,61 @@ class Router:
             s.ready.record(lane)
         s.round += 1
 
+    def _take(self, s):
+        """The engine's stream waits for the piece and, when the previous piece's answers are still leaving the status
+        buffer, for that."""
+        self.engine_stream.wait_event(s.ready)
+        if s.return_pending:
+            self.engine_stream.wait_event(s.returned)
+            s.return_pending = False
+
+    def status_buffer(self, s):
+        """Where the engine call that applies the piece handed out last writes its statuses: an int32 tensor of
+        max_recv words (pass it as d_status of join_batch_dev / fork_batch_dev), for return_statuses()."""
+        return s.status_piece
+
+    def return_statuses(self, s):
+        """After the engine call of the piece handed out last has been queued: every status of the piece goes back to
+        the rank its record came from (the reference answers every /v1/join and /v1/fork, ring.clj:54-69).  A
+        collective: every rank calls it once per piece, before taking the next piece."""
+        torch = self.torch
+        assert s.returned_rounds + 1 == s.round, "one return per piece, in order"
+        lane = self.stream if self.host_staged else self.comm_stream
+        with torch.cuda.stream(lane):
+            s.free.record(self.engine_stream)             # behind the engine call that writes the statuses
+            lane.wait_event(s.free)
+            if self.host_staged:
+                lane.synchronize()
+                back = torch.empty(s.ret_sorted.shape[0], dtype=torch.int32)
+                return_round(self.dist, self.group, self.rank, s.matrix, self.max_recv, s.round - 1, s.status_piece.cpu(), back)
+                _, send_off, send_cnt, _ = capi.route_plan(s.matrix, self.rank, self.max_recv, s.round - 1)
+                starts = np.concatenate([[0], np.cumsum(s.matrix[self.rank].astype(np.int64))[:-1]]).tolist()
+                for st, o, c in zip(starts, send_off, send_cnt):
+                    if c:
+                        s.ret_sorted[st + o:st + o + c].copy_(back[st + o:st + o + c])
+            else:
+                return_round(self.dist, self.group, self.rank, s.matrix, self.max_recv, s.round - 1, s.status_piece, s.ret_sorted)
+            s.returned.record(lane)
+        s.return_pending = True
+        s.returned_rounds += 1
+
+    def statuses(self, s, d_status_out, wait_stream=None):
+        """After the last piece's return_statuses() and before release(): d_status_out[i] (int32 tensor, n words) = the
+        answer to record i of the batch this rank gave start(), in its own submission order.  wait_stream (a torch
+        stream) is made to wait for them; without one the call itself waits."""
+        torch = self.torch
+        assert s.returned_rounds == s.rounds and s.rounds > 0, "every piece's statuses must have returned"
+        lane = self.stream if self.host_staged else self.comm_stream
+        with torch.cuda.stream(lane):
+            self.e._check(self.e.L.dj_scatter_statuses(self.e.h, s.n, s.origin.data_ptr(), s.ret_sorted.data_ptr(),
+                                                       d_status_out.data_ptr(), lane.cuda_stream))
+            s.home.record(lane)
+        s.home_pending = True
+        if wait_stream is not None:
+            wait_stream.wait_event(s.home)
+        else:
+            s.home.synchronize()
+
     def advance(self, s):
         """Exchange the first piece now (the host waits for the bucket sizes if they are not in yet).  Optional:
         finish() does it otherwise.  A collective: every rank calls it at the same point of its sequence."""
@@ -221,7 +311,7 @@ class Router:
         """-> (records for this rank, messages for this rank or None, n_received) of the first piece.  The
         engine's stream waits for the exchange; the host does not (beyond the bucket sizes)."""
         self.advance(s)
-        self.engine_stream.wait_event(s.ready)
+        self._take(s)
         return s.recv_recs, (s.recv_pay if s.has_pay else None), s.n_in
 
     def more(self, s):
@@ -232,7 +322,7 @@ class Router:
         """The next piece, into the same buffers: call after the engine call that consumes the previous
         piece has been queued.  A collective."""
         self._exchange(s)
-        self.engine_stream.wait_event(s.ready)
+        self._take(s)
         return s.recv_recs, (s.recv_pay if s.has_pay else None), s.n_in
 
     def release(self, s):

@@ -71,6 +71,12 @@ typedef struct dj_engine dj_engine;
                                           is stored with an empty message                           */
 #define DJ_JOIN_BAD_MAX_WAIT        7  /* 400: max_wait_s >= 2^29 (store.clj:27-28 with the engine's own
                                           limit; the reference's configured limits are 500..6000 s)  */
+/* With dj_set_join_hlen(e, 1) the status word of every event that was stored (WAITING, COMPLETE, NEAREST_NOT_QUEUED)
+ * also carries what redis/join returns as :count (redis.clj:137,157): HLEN of the barrier's hash right after this
+ * event's HSET, i.e. the number of positions that hold a message, whatever the metadata's :count says. */
+#define DJ_JOIN_HLEN_SHIFT 8
+#define DJ_JOIN_STATUS(word) ((int32_t)((word) & 0xFF))
+#define DJ_JOIN_HLEN(word)   ((uint32_t)(word) >> DJ_JOIN_HLEN_SHIFT)
 /* dj_fork_batch: core/fork (core.clj:24-33) */
 #define DJ_FORK_CREATED             1  /* 201, barrier created or fully reset (redis.clj:90-104)    */
 #define DJ_FORK_TABLE_FULL          2  /* engine limit: no free table slot                          */
@@ -342,6 +348,15 @@ int dj_checkpoint_load(dj_engine* e, const char* path);
  * Valid modes: -1 .. 23.  No reference counterpart. */
 int dj_set_hot_path(dj_engine* e, int mode);
 
+/* redis/join answers {:metadata m :count hlen} (redis.clj:137,157); core/join compares that HLEN with the metadata's
+ * :count (all-there?, core.clj:36-38).  The batch calls make that comparison on the device and answer WAITING or
+ * COMPLETE; a host that keeps core.clj as it is needs the number itself.  on = 1: every status word written by
+ * dj_join_batch / dj_join_batch_static for a stored event is `status | HLEN << DJ_JOIN_HLEN_SHIFT` (read with
+ * DJ_JOIN_STATUS / DJ_JOIN_HLEN; refused events keep their plain code).  HLEN can exceed :count after
+ * redis/update-metadata wrote a smaller :count back (redis.clj:106-111).  Barriers with many events in one batch are
+ * then always replayed event by event (the serial form), so leave it off (the default) where nobody reads the number. */
+int dj_set_join_hlen(dj_engine* e, int on);
+
 /* How a sweep finds what is due.  The reference pops a sorted set by score (redis.clj:283-289), which costs
  * what is due, not what is stored.  The engine has two forms with identical results: a scan of the queue
  * words (8 bytes per table slot), and a ready list that join batches append completed barriers to, with lower
@@ -382,6 +397,11 @@ int dj_partition_joins(dj_engine* e, uint32_t n, uint32_t n_ranks,
                        dj_join_rec* d_recs_out, uint8_t* d_payloads_out,
                        uint32_t* d_origin, uint32_t* d_counts, void* stream);
 
+/* The inverse of the partition's move, for per-record answers: d_out[d_origin[j]] = d_sorted[j] for j < n, where
+ * d_sorted[j] answers the record that dj_partition_joins put at place j.  Every origin index must be below the n of
+ * that partition call (they are, when d_origin is what it wrote).  stream as in dj_partition_joins. */
+int dj_scatter_statuses(dj_engine* e, uint32_t n, const uint32_t* d_origin, const int32_t* d_sorted, int32_t* d_out, void* stream);
+
 /* ---- the exchange itself (no counterpart in the reference, whose replicas share one Redis:
  * redis.clj:13-15) ------------------------------------------------------------------------------
  *
@@ -416,7 +436,8 @@ uint32_t dj_route_plan(uint32_t n_ranks, uint32_t rank, const uint32_t* matrix, 
  *                    records / messages, their number and whether more pieces follow (skew beyond max_recv).
  *                    Queue the engine call that consumes a piece before asking for the next one.
  *   dj_route_release after the last piece's engine call has been queued: the set may be reused.
- * Every rank makes the same calls in the same order.  A piece's record order: source rank 0's records in
+ * Every rank makes the same calls in the same order, and all ranks route a batch either with messages or without
+ * (d_payloads NULL on all or on none: a disagreement is reported by every rank's first dj_route_next / dj_route_advance).  A piece's record order: source rank 0's records in
  * array order, then rank 1's, ...: a fixed global order, so results do not depend on timing. */
 typedef struct dj_router dj_router;
 int  dj_route_unique_id(uint8_t* id128);
@@ -429,6 +450,24 @@ int  dj_route_advance(dj_router* r, int handle);
 int  dj_route_next(dj_router* r, int handle, const dj_join_rec** d_recs_out, const uint8_t** d_payloads_out,
                    uint32_t* n_out, int* more);
 int  dj_route_release(dj_router* r, int handle);
+
+/* The way back.  The reference answers every /v1/join and /v1/fork to the client that sent it (ring.clj:54-69: 202 with
+ * one of two texts core.clj:55,58; 404 / 400 redis.clj:152-153,159; 201 core.clj:32); with barriers sharded, the answer
+ * is computed on the owner's GPU and must return to the rank that holds the request.  Per piece:
+ *   dj_route_status_buffer  where the engine call that applies the piece handed out last writes its statuses (max_recv
+ *                           words of the handle's buffer set; pass it as d_status of dj_join_batch / dj_fork_batch).
+ *   dj_route_return         after that engine call has been queued: sends every status of the piece to the rank its record
+ *                           came from (4 bytes per record, one grouped send / receive over the same plan read backwards, on
+ *                           the router's communication stream behind an event on the engine's stream; the host does not
+ *                           wait).  A collective like dj_route_next: every rank calls it once per piece, in order, before
+ *                           asking for the next piece.
+ * and once per batch, after the last piece's dj_route_return and before dj_route_release:
+ *   dj_route_statuses       d_status_out[i] = the answer to record i of the batch this rank gave dj_route_start (n words,
+ *                           this rank's own submission order; device memory).  `stream`: a hipStream_t that is made to wait
+ *                           for the answers (read them from work ordered behind it), or NULL: the call itself waits. */
+int  dj_route_status_buffer(dj_router* r, int handle, int32_t** d_status_piece);
+int  dj_route_return(dj_router* r, int handle);
+int  dj_route_statuses(dj_router* r, int handle, int32_t* d_status_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,8 @@
 // Every rank routes B batches of n records with their messages; a share of all records names one hot barrier, so its
 // owner's incoming rows exceed max_recv and every batch takes several rounds.  Checked per rank and batch: the pieces,
 // put one behind the other, are exactly the records this rank owns (dj_owner_of) from rank 0's batch in array order,
-// then from rank 1's, ..., each with its message.  Batches are started ahead (two in flight) and every other batch's
+// then from rank 1's, ..., each with its message; and the answers to them (one word per record, here a function of the
+// record) come back to the rank that submitted the record, in its own submission order.  Batches are started ahead (two in flight) and every other batch's
 // first piece is sent ahead of its use (dj_route_advance), as a pipelined host would.
 //
 //   usage: router_ranks <ranks> <records per rank and batch> <max_recv> <hot percent> [batches]
@@ -44,6 +45,9 @@ static dj_join_rec make_rec(int r, int b, uint32_t i, int hot_percent) {
     j.max_wait_s = (uint32_t)b;
     return j;
 }
+
+// what the stand-in for the engine call answers to record i of rank r's batch b
+static int32_t answer_of(const dj_join_rec& j) { return (int32_t)(mix(((uint64_t)j.len << 40) ^ ((uint64_t)j.max_wait_s << 32) ^ j.position) & 0x7FFFFFFF); }
 
 static void make_msg(uint8_t* row, int r, int b, uint32_t i) {
     uint64_t x = mix(((uint64_t)r << 48) ^ ((uint64_t)b << 40) ^ i ^ 0xABCDEF);
@@ -110,6 +114,9 @@ int main(int argc, char** argv) {
                 HIP_OK(hipMemcpy(d_recs[b], h.data(), (size_t)n * sizeof(dj_join_rec), hipMemcpyHostToDevice));
                 HIP_OK(hipMemcpy(d_pay[b], hp.data(), (size_t)n * PITCH, hipMemcpyHostToDevice));
             }
+            int32_t* d_answers = nullptr;
+            HIP_OK(hipMalloc((void**)&d_answers, (size_t)n * 4));
+            HIP_OK(hipMemset(d_answers, 0xFF, (size_t)n * 4));
             std::vector<int> handle(B, -1);
             auto start = [&](int b) {
                 if (dj_route_start(rt, n, d_recs[b], d_pay[b], &handle[b]) != DJ_OK) {
@@ -146,7 +153,27 @@ int main(int argc, char** argv) {
                         HIP_OK(hipMemcpy(&got[at], pr, (size_t)pn * sizeof(dj_join_rec), hipMemcpyDeviceToHost));
                         HIP_OK(hipMemcpy(&got_pay[at * PITCH], pp, (size_t)pn * PITCH, hipMemcpyDeviceToHost));
                     }
+                    // the way back: the "engine call" writes one answer per received record, the router returns them
+                    int32_t* d_st = nullptr;
+                    if (dj_route_status_buffer(rt, handle[b], &d_st) != DJ_OK) { fprintf(stderr, "rank %d: status buffer: %s\n", r, dj_router_last_error(rt)); exit(2); }
+                    std::vector<int32_t> ans(pn);
+                    for (uint32_t k = 0; k < pn; ++k) ans[k] = answer_of(got[at + k]);
+                    if (pn) HIP_OK(hipMemcpyAsync(d_st, ans.data(), (size_t)pn * 4, hipMemcpyHostToDevice, (hipStream_t)dj_stream(e)));
+                    HIP_OK(hipStreamSynchronize((hipStream_t)dj_stream(e)));      // (ans lives on this thread's stack frame)
+                    if (dj_route_return(rt, handle[b]) != DJ_OK) { fprintf(stderr, "rank %d: return: %s\n", r, dj_router_last_error(rt)); exit(2); }
                     ++rounds;
+                }
+                {   // every record of this rank's own batch has its answer, in the order the batch was submitted
+                    if (dj_route_statuses(rt, handle[b], d_answers, nullptr) != DJ_OK) { fprintf(stderr, "rank %d: statuses: %s\n", r, dj_router_last_error(rt)); exit(2); }
+                    std::vector<int32_t> back(n);
+                    HIP_OK(hipMemcpy(back.data(), d_answers, (size_t)n * 4, hipMemcpyDeviceToHost));
+                    for (uint32_t i = 0; i < n; ++i)
+                        if (back[i] != answer_of(make_rec(r, b, i, hot))) {
+                            fprintf(stderr, "rank %d batch %d: the answer to record %u is %d, not %d\n", r, b, i, back[i], answer_of(make_rec(r, b, i, hot)));
+                            ++sh.failures;
+                            break;
+                        }
+                    HIP_OK(hipMemset(d_answers, 0xFF, (size_t)n * 4));
                 }
                 if (dj_route_release(rt, handle[b]) != DJ_OK) { fprintf(stderr, "rank %d: release: %s\n", r, dj_router_last_error(rt)); exit(2); }
                 if (rounds > rounds_seen[r]) rounds_seen[r] = rounds;
@@ -172,6 +199,7 @@ int main(int argc, char** argv) {
             barrier(sh, N);
             dj_router_destroy(rt);
             for (int b = 0; b < B; ++b) { (void)hipFree(d_recs[b]); (void)hipFree(d_pay[b]); }
+            (void)hipFree(d_answers);
             dj_destroy(e);
         });
     for (auto& t : th) t.join();
@@ -180,6 +208,6 @@ int main(int argc, char** argv) {
     for (uint32_t x : rounds_seen)
         if (x != most) { fprintf(stderr, "ranks took different numbers of rounds\n"); ++sh.failures; }
     printf("ranks %d, %u records per rank and batch, %d batches, max_recv %u, hot %d %%: %u rounds per batch at most, %s\n", N, n, B,
-           max_recv, hot, most, sh.failures.load() ? "FAILED" : "every rank received its records in order");
+           max_recv, hot, most, sh.failures.load() ? "FAILED" : "every rank received its records in order and every record's answer came back");
     return sh.failures.load() ? 1 : 0;
 }

@@ -62,6 +62,34 @@ def test_sweep_with_an_earlier_clock_leaves_completed_barriers_queued(oracle_lib
     e.close()
 
 
+def test_drained_list_entry_that_is_not_due_yet_is_popped_by_the_next_sweep(oracle_lib):
+    """The drain form proper: a first sweep clears the "list incomplete" state that set_sweep_path leaves, so the sweeps
+    that follow drain the list and read region bounds.  A barrier completed at T0 + 100 and met by a sweep whose clock
+    is earlier must come out of the first sweep at or after T0 + 100 (ZRANGEBYSCORE 0 now, redis.clj:286), not at its
+    fork deadline."""
+    e, o, d = _pair(oracle_lib, 300)
+    ec, oc = d.sweep(T0 + 1)                    # a full scan: bounds recomputed, the list is complete from here on
+    assert len(ec) == 0
+    _complete(d, np.arange(0, 200), 2, T0 + 100)
+    ec, oc = d.sweep(T0 + 50)                   # the list's entries are not due: it is emptied all the same
+    assert len(ec) == 0
+    ec, oc = d.sweep(T0 + 99)
+    assert len(ec) == 0
+    ec, oc = d.sweep(T0 + 100)
+    assert len(ec) == 200
+    d.ack(ec, oc, lambda k: True, T0 + 101)
+    # the same with two clocks that leapfrog: every completion must be popped by the first sweep at or after its date
+    for r in range(4):
+        which = np.arange(200 + 25 * r, 225 + 25 * r)
+        _complete(d, which, 2, T0 + 200 + 10 * r)
+        ec, oc = d.sweep(T0 + 195 + 10 * r)     # five milliseconds behind the joins' clock
+        assert len(ec) == (25 if r else 0)      # the previous round's barriers
+        d.ack(ec, oc, lambda k: True, T0 + 196 + 10 * r)
+    ec, oc = d.sweep(T0 + 300)
+    assert len(ec) == 25
+    e.close()
+
+
 def test_ready_list_overflow_falls_back_to_the_scan(oracle_lib):
     # max_batch 256: the list's shards hold 64 slots each and a batch of 256 events uses four of them
     n = 3000

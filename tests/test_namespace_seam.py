@@ -189,14 +189,29 @@ def run_commands(view, seed, n_steps):
     r.clock = lambda: clock[0]
     core = CoreService(view, lambda: clock[0], None, env=r.env).core
     ids = [f"c{k}~x" for k in range(5)]
-    log = []
+    log, hlens = [], []
     for t, kind, arg in command_stream(seed, n_steps):
         clock[0] = T0 + t
         try:
             if kind == "fork":
-                out = core.fork(arg)
+                # redis/fork itself, then what core.clj:30 calls next (the engine's fork has applied it already)
+                ts = clock[0] + 1000 * arg["max-wait"]
+                out = r.fork(dict(arg, **{"timeout-secs": ts}))
+                r.store_in_publish_queue(out, ts)
             elif kind == "join":
-                out = core.join(arg)
+                # redis/join itself: {:metadata m :count HLEN} (redis.clj:137,157), HLEN past the metadata's count included;
+                # then the calls core.clj:52-58 makes next (the engine's join has applied them already)
+                resp = r.join(arg)
+                out = ["join", resp["count"], resp["metadata"]]
+                hlens.append((resp["count"], (resp["metadata"] or {}).get("count")))
+                if core.all_there(arg["barrier-id"], resp["metadata"], resp["count"]):
+                    r.store_in_publish_queue(arg["barrier-id"], clock[0])
+                    out.append("complete")
+                elif arg.get("max-wait"):
+                    try:
+                        out.append(r.store_nearest_in_publish_queue(arg["barrier-id"], clock[0] + 1000 * arg["max-wait"]))
+                    except StoreError as ex:
+                        out.append(("error", str(ex), sorted(ex.data)))
             elif kind == "all_joins":
                 md = r.join_metadata(arg)
                 out = r.all_joins(arg, md["count"] if md else None)
@@ -214,7 +229,11 @@ def run_commands(view, seed, n_steps):
             md = r.join_metadata(i)
             state.append((i, md, view.queue_scores(i), None if md is None else r.all_joins_status(i, md["count"])))
         log.append((kind, arg, out, state))
+    log.append(("hlen", hlens))
     return log
+
+
+seen_past_count = []
 
 
 @pytest.mark.gpu
@@ -228,6 +247,9 @@ def test_namespace_functions_called_directly_against_the_oracle(seed, oracle_lib
         got = run_commands(engine_view(env, None, engines), seed, 300)
         for k, (w, g) in enumerate(zip(want, got)):
             assert w == g, f"seed {seed} step {k}:\noracle {w}\nengine {g}"
+        seen_past_count.append(any(h > c for h, c in want[-1][1] if c is not None))
+        if seed == 5:
+            assert any(seen_past_count), "no stream had a join answer HLEN above the metadata's count"
     finally:
         for e in engines:
             e.close()
@@ -268,6 +290,7 @@ def test_poll_cap_on_the_engine_at_both_seams():
         _poll_that_outlasts_its_cap(CoreService, engine_view(dict(DEFAULT_ENV), lambda: clock[0], engines), clock)
         clock = [T0]
         view = engine_view(dict(DEFAULT_ENV), None, engines)
+        view.redis.e.set_join_hlen(False)          # the batch seam reads plain status codes
         _poll_that_outlasts_its_cap(ForkJoinService, EngineStore(view.redis.e), clock)
     finally:
         for e in engines:

@@ -22,6 +22,24 @@ def test_native_router_with_several_ranks(ranks, n, max_recv, hot):
     env["LD_LIBRARY_PATH"] = DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
     p = subprocess.run([exe, str(ranks), str(n), str(max_recv), str(hot)], env=env, capture_output=True, text=True, timeout=240)
     assert p.returncode == 0, p.stdout + p.stderr
-    assert "every rank received its records in order" in p.stdout
+    assert "every rank received its records in order and every record's answer came back" in p.stdout
     rounds = int(p.stdout.split(":")[-1].split("rounds")[0])
+    assert (rounds > 1) == (hot > 0), p.stdout
+
+
+@pytest.mark.parametrize("ranks,nb,n,max_recv,hot", [(2, 3000, 20000, 8192, 50), (3, 1500, 9000, 100000, 0), (4, 1500, 12000, 4096, 40),
+                                                      (8, 800, 8000, 4096, 60)])
+def test_native_router_brings_every_answer_home(ranks, nb, n, max_recv, hot):
+    """Routed mode end to end behind the C ABI (tests/rccl_standin/router_answers.cpp): forks and joins go to their
+    owners' engines, every record's answer returns to the rank that submitted it (dj_route_return / dj_route_statuses),
+    and each rank's answers, in its own submission order, are one oracle store's on the concatenated stream — with a
+    hot barrier that forces rounds, ids nobody forked (404) and positions beyond the count (400)."""
+    exe, lib = os.path.join(DIR, "router_answers"), os.path.join(DIR, "librccl.so.1")
+    assert os.path.exists(exe) and os.path.exists(lib), "run __graft_entry__.build() first"
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    p = subprocess.run([exe, str(ranks), str(nb), str(n), str(max_recv), str(hot)], env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "every rank got one store's answers" in p.stdout
+    rounds = int(p.stdout.split("due at the end,")[-1].split("rounds")[0])
     assert (rounds > 1) == (hot > 0), p.stdout
