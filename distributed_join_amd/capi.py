@@ -74,7 +74,8 @@ SYMBOLS = ["dj_create", "dj_destroy", "dj_last_error", "dj_sync", "dj_stream", "
            "dj_set_sweep_path", "dj_route_plan", "dj_route_unique_id", "dj_router_create", "dj_router_destroy",
            "dj_router_last_error", "dj_route_start", "dj_route_advance", "dj_route_next", "dj_route_release",
            "dj_complete_one", "dj_update_metadata_one", "dj_store_nearest_in_publish_queue", "dj_unprocessed",
-           "dj_set_join_hlen", "dj_scatter_statuses", "dj_route_status_buffer", "dj_route_return", "dj_route_statuses"]
+           "dj_set_join_hlen", "dj_scatter_statuses", "dj_route_status_buffer", "dj_route_return", "dj_route_statuses",
+           "dj_measure_copy"]
 # include/dj_batcher.h
 BATCHER_SYMBOLS = ["dj_batcher_create", "dj_batcher_destroy", "dj_batcher_set_clock", "dj_batcher_join",
                    "dj_batcher_fork", "dj_batcher_join_wait", "dj_batcher_fork_wait", "dj_batcher_run",
@@ -228,6 +229,9 @@ def load():
     L.dj_batcher_run.argtypes = [vp, TASK_CB, vp]
     L.dj_batcher_get_stats.restype = i32
     L.dj_batcher_get_stats.argtypes = [vp, ctypes.POINTER(BatcherStats)]
+    if not os.environ.get("DJ_ENGINE_LIB") or hasattr(L, "dj_measure_copy"):
+        L.dj_measure_copy.restype = i32
+        L.dj_measure_copy.argtypes = [vp, u64, u32, ctypes.POINTER(ctypes.c_double)]
     L.dj_compact.restype = i32
     L.dj_compact.argtypes = [vp, ctypes.POINTER(u64)]
     L.dj_profile_enable.restype = i32

@@ -1313,3 +1313,35 @@ extern "C" int dj_scatter_statuses(dj_engine* e, uint32_t n, const uint32_t* d_o
     HIP_TRY(e, hipGetLastError());
     return DJ_OK;
 }
+
+extern "C" int dj_measure_copy(dj_engine* e, uint64_t bytes, uint32_t iterations, double* h_gbps) {
+    if (!e || !h_gbps || bytes < (1u << 20) || iterations < 1) return DJ_E_INVALID;
+    std::lock_guard<std::recursive_mutex> guard(e->mu);
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    bytes &= ~(uint64_t)15;
+    void *src = nullptr, *dst = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    auto body = [&]() -> int {
+        if (hipMalloc(&src, bytes) != hipSuccess || hipMalloc(&dst, bytes) != hipSuccess) return fail(e, DJ_E_NOMEM, "measure_copy: no room for two buffers of %llu bytes", (unsigned long long)bytes);
+        HIP_TRY(e, hipMemsetAsync(src, 1, bytes, e->stream));
+        HIP_TRY(e, hipEventCreate(&a));
+        HIP_TRY(e, hipEventCreate(&b));
+        const uint32_t blocks = e->n_cus * 8;
+        stream_copy_kernel<<<blocks, 256, 0, e->stream>>>((const uint4*)src, (uint4*)dst, bytes / 16);      // warm-up
+        HIP_TRY(e, hipEventRecord(a, e->stream));
+        for (uint32_t k = 0; k < iterations; ++k) stream_copy_kernel<<<blocks, 256, 0, e->stream>>>((const uint4*)src, (uint4*)dst, bytes / 16);
+        HIP_TRY(e, hipEventRecord(b, e->stream));
+        HIP_TRY(e, hipGetLastError());
+        HIP_TRY(e, hipEventSynchronize(b));
+        float ms = 0;
+        HIP_TRY(e, hipEventElapsedTime(&ms, a, b));
+        *h_gbps = ms > 0 ? 2.0 * (double)bytes * iterations / (ms * 1e-3) / 1e9 : 0.0;      // bytes read + bytes written
+        return DJ_OK;
+    };
+    const int rc = body();
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    (void)hipFree(src);
+    (void)hipFree(dst);
+    return rc;
+}

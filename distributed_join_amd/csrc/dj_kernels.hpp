@@ -1539,18 +1539,65 @@ __global__ void __launch_bounds__(256) pop_ready_kernel(Table t, Work w, uint64_
     }
 }
 
+// The due slots a block has found and not yet worked off.  A block collects them over ALL the chunks it scans and
+// works them off in rounds of 256 (one slot per thread), so the cursor atomic is paid once per 256 due slots and
+// once more per block at the end — not once per chunk: on a large table with few due slots per chunk (65 536 due
+// among 32 M slots: 8 per chunk of 4096) the per-chunk form queued 8192 returning atomics on the one cursor word,
+// about 100 us of the pass whatever the scan itself took.
+constexpr uint32_t POP_CHUNK = 256 * POP_ITEMS;
+struct PopList {
+    uint32_t slot[POP_CHUNK + 256];      // a round's remainder (< 256) plus one chunk's worth
+    uint32_t n;
+};
+
+// Appends the slots cb + j * 256 + tid of the bits set in due_mask (wave-cooperative: one LDS atomic per wave).
+__device__ inline void pop_list_append(PopList& L, uint32_t due_mask, uint64_t slot0, uint32_t step) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t nd = (uint32_t)__popc(due_mask);
+    const uint32_t incl = wave_incl_scan(nd);
+    const uint32_t wtot = __shfl(incl, 63);
+    if (wtot == 0) return;                      // uniform across the wave
+    uint32_t wbase = 0;
+    if (lane == 63) wbase = atomicAdd(&L.n, wtot);
+    wbase = __shfl(wbase, 63);
+    uint32_t at = wbase + incl - nd;
+    for (uint32_t mk = due_mask; mk; mk &= mk - 1) L.slot[at++] = (uint32_t)(slot0 + (uint64_t)(__ffs(mk) - 1) * step);
+}
+
+// Works off whole rounds of 256 listed slots (all of them with `rest`).  Called by every thread of the block after a
+// barrier that made the appends visible; leaves fewer than 256 entries at the front of the list (none with `rest`).
+__device__ inline void pop_list_drain(const Table& t, const Work& w, PopList& L, PopShared& sh, bool rest, uint64_t now,
+                                      uint32_t cap_conts, uint64_t cap_pos, int alloc_pos, dj_cont* conts) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t ln = L.n;                    // the same in every thread
+    uint32_t r = 0;
+    for (; r + 256 <= ln || (rest && r < ln); r += 256) {       // uniform across the block
+        const bool has = r + tid < ln;
+        uint64_t s = 0, pa = 0;
+        if (has) {
+            s = L.slot[r + tid];
+            pa = t.q[s];
+        }
+        pop_emit_round(t, w, sh, has, s, pa, false, now, cap_conts, cap_pos, alloc_pos, conts);
+    }
+    const uint32_t rem = r < ln ? ln - r : 0;   // < 256
+    const uint32_t keep = tid < rem ? L.slot[r + tid] : 0;
+    __syncthreads();
+    if (tid < rem) L.slot[tid] = keep;
+    if (tid == 0) L.n = rem;
+    __syncthreads();
+}
+
 // scan form of engines without a ready list
 __device__ inline void pop_due_body(const Table& t, const Work& w, uint64_t now, uint32_t cap_conts,
                                                       uint64_t cap_pos, int alloc_pos, dj_cont* conts) {
-    __shared__ uint16_t list[256 * POP_ITEMS];     // offsets of the chunk's due slots
-    __shared__ uint32_t list_n;
+    __shared__ PopList L;
     __shared__ PopShared sh;
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t tid = threadIdx.x;
     const uint64_t nslots = t.mask + 1;
-    const uint64_t chunk = 256ull * POP_ITEMS;
-    for (uint64_t cb = blockIdx.x * chunk; cb < nslots; cb += (uint64_t)gridDim.x * chunk) {
-        if (tid == 0) list_n = 0;
-        __syncthreads();
+    if (tid == 0) L.n = 0;
+    __syncthreads();
+    for (uint64_t cb = blockIdx.x * (uint64_t)POP_CHUNK; cb < nslots; cb += (uint64_t)gridDim.x * POP_CHUNK) {
         uint32_t due_mask = 0;
 #pragma unroll
         for (int j = 0; j < POP_ITEMS; ++j) {
@@ -1558,30 +1605,11 @@ __device__ inline void pop_due_body(const Table& t, const Work& w, uint64_t now,
             const uint64_t qv = s < nslots ? t.q[s] : NQ;
             if (qv <= now) due_mask |= 1u << j;
         }
-        const uint32_t nd = (uint32_t)__popc(due_mask);
-        const uint32_t incl = wave_incl_scan(nd);
-        const uint32_t wtot = __shfl(incl, 63);
-        if (wtot) {                                 // uniform across the wave
-            uint32_t wbase = 0;
-            if (lane == 63) wbase = atomicAdd(&list_n, wtot);
-            wbase = __shfl(wbase, 63);
-            uint32_t at = wbase + incl - nd;
-            for (uint32_t mk = due_mask; mk; mk &= mk - 1)
-                list[at++] = (uint16_t)((__ffs(mk) - 1) * 256 + tid);
-        }
+        pop_list_append(L, due_mask, cb + tid, 256);
         __syncthreads();
-        const uint32_t ln = list_n;
-        for (uint32_t r = 0; r < ln; r += 256) {    // uniform across the block
-            const uint32_t e = r + tid;
-            const bool has = e < ln;
-            uint64_t s = 0, pa = 0;
-            if (has) {
-                s = cb + list[e];
-                pa = t.q[s];
-            }
-            pop_emit_round(t, w, sh, has, s, pa, false, now, cap_conts, cap_pos, alloc_pos, conts);
-        }
+        pop_list_drain(t, w, L, sh, false, now, cap_conts, cap_pos, alloc_pos, conts);
     }
+    pop_list_drain(t, w, L, sh, true, now, cap_conts, cap_pos, alloc_pos, conts);
 }
 
 // (at most 80 scalar registers: from 82 on a compute unit admits seven blocks of 256 threads instead of eight)
@@ -1639,18 +1667,17 @@ __global__ void __launch_bounds__(SELECT_BLOCK) select_regions_kernel(Table t, W
 // queue words; wave wv reads region 4 j + wv of the 64 in step j), the regions' numbers in LDS
 __global__ void __launch_bounds__(256) pop_regions_kernel(Table t, Work w, uint64_t now, uint32_t cap_conts,
                                                           uint64_t cap_pos, int alloc_pos, dj_cont* conts) {
-    __shared__ uint16_t list[256 * POP_ITEMS];
-    __shared__ uint32_t list_n;
+    __shared__ PopList L;
     __shared__ uint32_t reg[64];
     __shared__ PopShared sh;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint64_t nr = w.sweep[S_REGIONS];          // 0 unless pass 1 found it was its turn
     uint64_t later = NQ;
+    if (tid == 0) L.n = 0;
+    __syncthreads();
     for (uint64_t c0 = (uint64_t)blockIdx.x * 64; c0 < nr; c0 += (uint64_t)gridDim.x * 64) {
-        if (tid == 0) list_n = 0;
         if (tid < 64) reg[tid] = c0 + tid < nr ? w.regions[c0 + tid] : 0xFFFFFFFFu;
         __syncthreads();
-        uint32_t due_mask = 0;
         uint64_t qv[POP_ITEMS];
 #pragma unroll
         for (int j = 0; j < POP_ITEMS; ++j) {
@@ -1659,7 +1686,6 @@ __global__ void __launch_bounds__(256) pop_regions_kernel(Table t, Work w, uint6
         }
 #pragma unroll
         for (int j = 0; j < POP_ITEMS; ++j) {
-            if (qv[j] <= now) due_mask |= 1u << j;
             // the region's new bound: the smallest score beyond now that stays (popped and absent entries have bit 63
             // set; what is due goes, or lowers the bound again where it does not fit the caller's buffers)
             uint64_t m = (qv[j] > now && !(qv[j] >> 63)) ? qv[j] : NQ;
@@ -1672,33 +1698,19 @@ __global__ void __launch_bounds__(256) pop_regions_kernel(Table t, Work w, uint6
                 a_store(&t.qmin[r], (unsigned long long)m);
                 if (m < later) later = m;
             }
-        }
-        const uint32_t nd = (uint32_t)__popc(due_mask);
-        const uint32_t incl = wave_incl_scan(nd);
-        const uint32_t wtot = __shfl(incl, 63);
-        if (wtot) {                                 // uniform across the wave
-            uint32_t wbase = 0;
-            if (lane == 63) wbase = atomicAdd(&list_n, wtot);
-            wbase = __shfl(wbase, 63);
-            uint32_t at = wbase + incl - nd;
-            for (uint32_t mk = due_mask; mk; mk &= mk - 1)
-                list[at++] = (uint16_t)((__ffs(mk) - 1) * 256 + tid);
+            // the region's due slots onto the block's list (every lane of the wave reads the same region: one append per step)
+            const uint64_t dm = __ballot(qv[j] <= now);
+            if (dm) {
+                uint32_t wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&L.n, (uint32_t)__popcll(dm));
+                wbase = __shfl(wbase, 0);
+                if (qv[j] <= now) L.slot[wbase + (uint32_t)__popcll(dm & ((1ull << lane) - 1))] = (r << REGION_SHIFT) + lane;
+            }
         }
         __syncthreads();
-        const uint32_t ln = list_n;
-        for (uint32_t r = 0; r < ln; r += 256) {    // uniform across the block
-            const uint32_t e = r + tid;
-            const bool has = e < ln;
-            uint64_t s = 0, pa = 0;
-            if (has) {
-                const uint32_t code = list[e];      // step * 256 + thread
-                s = ((uint64_t)reg[(code >> 8) * 4 + ((code & 255) >> 6)] << REGION_SHIFT) + (code & 63);
-                pa = t.q[s];
-            }
-            pop_emit_round(t, w, sh, has, s, pa, false, now, cap_conts, cap_pos, alloc_pos, conts);
-        }
-        __syncthreads();                            // reg[] and list[] are rewritten by the next round of regions
+        pop_list_drain(t, w, L, sh, false, now, cap_conts, cap_pos, alloc_pos, conts);     // (its barriers also guard reg[])
     }
+    pop_list_drain(t, w, L, sh, true, now, cap_conts, cap_pos, alloc_pos, conts);
     if (later != NQ && later < a_load(w.due_next))   // lane 0 of each wave carries the regions' new bounds
         __hip_atomic_fetch_min(w.due_next, (unsigned long long)later, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -2381,6 +2393,18 @@ __global__ void __launch_bounds__(PART_BLOCK) partition_scatter_kernel(const dj_
 __global__ void __launch_bounds__(256) scatter_statuses_kernel(uint32_t n, const uint32_t* origin, const int32_t* sorted, int32_t* out) {
     for (uint64_t j = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; j < n; j += (uint64_t)gridDim.x * blockDim.x)
         out[origin[j]] = sorted[j];
+}
+
+// Measurement aid: a plain streaming copy, 16 bytes per lane, four loads in flight per thread before the first store.
+// What this GPU's memory delivers to the simplest possible kernel is the ceiling the byte-moving passes are held against.
+__global__ void __launch_bounds__(256) stream_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n16) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
 }
 
 }  // namespace dj

@@ -339,6 +339,12 @@ class Engine:
         self._check(self.L.dj_compact(self.h, ctypes.byref(live)))
         return live.value
 
+    def measure_copy(self, nbytes=1 << 30, iterations=5):
+        """GB/s (read + written) of the library's plain 16-bytes-per-lane copy kernel on this GPU."""
+        out = ctypes.c_double(0.0)
+        self._check(self.L.dj_measure_copy(self.h, int(nbytes), int(iterations), ctypes.byref(out)))
+        return out.value
+
     def profile_enable(self, on=True):
         self._check(self.L.dj_profile_enable(self.h, 1 if on else 0))
 

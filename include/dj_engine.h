@@ -379,6 +379,11 @@ int dj_profile_enable(dj_engine* e, int on);
  * each kernel since the previous read, or -1 when it was not launched. */
 int dj_profile_read(dj_engine* e, float* h_ms);
 
+/* The streaming rate of this GPU's memory as the library's own plainest kernel sees it (16 bytes per lane copied from one
+ * buffer of `bytes` bytes to another, `iterations` times after a warm-up; both buffers are allocated and freed by the
+ * call, which waits): *h_gbps = (bytes read + bytes written) / time in GB/s.  Measurement aid, no reference counterpart. */
+int dj_measure_copy(dj_engine* e, uint64_t bytes, uint32_t iterations, double* h_gbps);
+
 /* ---- multi-GPU routing helper (device pointers) ---------------------------------- */
 
 /* owner rank of a barrier among n_ranks engines */

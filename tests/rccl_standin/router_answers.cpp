@@ -114,7 +114,11 @@ int main(int argc, char** argv) {
             ec.arena_bytes = (uint64_t)(total + 64) * 1024 + (4u << 20);
             ec.max_count = 8;
             ec.payload_stride = PITCH;
-            ec.max_batch = (n > NB + 1 ? n : NB + 1) > 4096 ? (n > NB + 1 ? n : NB + 1) : 4096;
+            // a piece holds at most max_recv rows, and never more than all ranks submit together
+            uint32_t piece = (uint64_t)N * (n > NB + 1 ? n : NB + 1) < max_recv ? (uint32_t)N * (n > NB + 1 ? n : NB + 1) : max_recv;
+            ec.max_batch = piece > 4096 ? piece : 4096;
+            if (ec.max_batch < n) ec.max_batch = n;
+            if (ec.max_batch < NB + 1) ec.max_batch = NB + 1;
             ec.check_publish_delay_ms = 10000;
             ec.max_retry_publish = 3;
             ec.max_retry_timeout_publish = 3;
@@ -123,7 +127,7 @@ int main(int argc, char** argv) {
             if (r == 0 && dj_route_unique_id(sh.id) != DJ_OK) { fprintf(stderr, "id: %s\n", dj_router_last_error(nullptr)); exit(2); }
             barrier(sh, N);
             dj_router* rt = nullptr;
-            if (dj_router_create(e, (uint32_t)N, (uint32_t)r, sh.id, ec.max_batch, max_recv, PITCH, 3, &rt) != DJ_OK) {
+            if (dj_router_create(e, (uint32_t)N, (uint32_t)r, sh.id, n > NB + 1 ? n : NB + 1, max_recv, PITCH, 3, &rt) != DJ_OK) {
                 fprintf(stderr, "rank %d: router: %s\n", r, dj_router_last_error(nullptr));
                 exit(2);
             }
