@@ -62,6 +62,10 @@ def parse():
     ap.add_argument("--recv-cap", type=int, default=0,
                     help="experiment: rows a rank's receive buffers hold (default: 2 x batch); smaller values make the exchange "
                          "take several rounds")
+    ap.add_argument("--capacity", type=int, default=0,
+                    help="experiment: the engine's capacity_barriers (table slots = next power of two >= 2x), default: --barriers; "
+                         "a large value gives a table that no cache holds while the batches stay at --barriers events")
+    ap.add_argument("--hot-path", type=int, default=-1, help="experiment: dj_set_hot_path mode (8: never the bucketed join passes, 16: wherever they apply)")
     ap.add_argument("--route", action="store_true",
                     help="run the multi-GPU routing path (partition + all-to-all) even with one rank")
     return ap.parse_args()
@@ -334,11 +338,13 @@ def main():
     slab_bytes = 64 * (1 + (8 * (1 << (c - 1).bit_length()) + 63) // 64) + (1 << (c - 1).bit_length()) * stride
     recv_cap = batch if world == 1 else int(batch * 1.25) + 4096       # hash imbalance headroom
     # capacity nb -> 2 * nb slots at every N (a rank owns nb +- 0.3 % of the global barrier space)
-    eng = Engine(capacity_barriers=nb,
+    eng = Engine(capacity_barriers=max(nb, a.capacity),
                  arena_bytes=int(nb * (1.0 if world == 1 else 1.3) * (slab_bytes + 64)) + (64 << 20),
                  max_count=max(c, a.max_count),
                  payload_stride=stride, max_batch=max(recv_cap, nb * 2 if world > 1 else nb), device=local,
                  max_message_bytes=a.max_message)
+    if a.hot_path >= 0:
+        eng.set_hot_path(a.hot_path)
     cap_conts = int(nb * (1.0 if world == 1 else 1.3)) + 1024
     cap_pos = cap_conts * c
     d_conts = eng.empty(cap_conts * capi.CONT.itemsize)
@@ -526,7 +532,7 @@ def main():
         dom = max((k for k in kernels if kernels[k]["alg_bytes_per_launch"] > 0), key=lambda k: kernels[k]["total_ms"])
         traffic = traffic_detail = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf) and (nb, c, P, world) == (1 << 20, 8, 64, 1) and not routed and a.hot_frac == 0 and not a.max_message and not a.max_count and not a.join_max_wait and not a.zipf_frac:
+        if os.path.exists(tf) and (nb, c, P, world) == (1 << 20, 8, 64, 1) and not routed and a.hot_frac == 0 and not a.max_message and not a.max_count and not a.join_max_wait and not a.zipf_frac and not a.capacity and a.hot_path < 0:
             # the counters were collected on this workload
             with open(tf) as f:
                 traffic_detail = json.load(f).get(dom)

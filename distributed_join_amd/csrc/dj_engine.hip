@@ -628,10 +628,12 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
     // rank, which comes a little above or below 2^20, stays in this form), on tables of up to 2^22 slots (the second pass finds the lines
     // that the first one fetched in the 256 MB Infinity Cache as long as not much more than the table competes for it:
     // with batches applied in pieces of 2^20 events the bucketed form gained 7 % on a table of 2^21 slots, lost 1 % at
-    // 2^22 and 9 % at 2^23 and 2^25), and whose previous batch showed no long chains (a hot barrier overflows its bucket, and the batch then falls back to chains).
+    // 2^22 and 9 % at 2^23 and 2^25: that was a batch of 2^22 events cut into pieces, which costs the chain form's gain from
+    // large launches; a batch that IS about 2^20 events gains on a table of any size — 2^25 slots, link + resolve: 132 us
+    // chained, 121 us bucketed), and whose previous batch showed no long chains (a hot barrier overflows its bucket, and the batch then falls back to chains).
     const uint64_t slots = e->t.mask + 1;
     bool bucket = !serial_only && w.fused && !wide && n <= BK_MAX_BUCKETS * BK_MEAN_MAX && e->bucket_mode != 0 &&
-                  (e->bucket_mode == 1 || (n >= 196608 && slots <= (1ull << 22) && hint[0] < 2048 && hint[1] < 512));
+                  (e->bucket_mode == 1 || (n >= 196608 && hint[0] < 2048 && hint[1] < 512));
     if (bucket) {
         uint32_t B = 16;
         while (B < BK_MAX_BUCKETS && (uint64_t)B * 512 < n) B <<= 1;
