@@ -75,9 +75,9 @@ SYMBOLS = ["dj_create", "dj_destroy", "dj_last_error", "dj_sync", "dj_stream", "
            "dj_router_last_error", "dj_route_start", "dj_route_advance", "dj_route_next", "dj_route_release",
            "dj_complete_one", "dj_update_metadata_one", "dj_store_nearest_in_publish_queue", "dj_unprocessed",
            "dj_set_join_hlen", "dj_scatter_statuses", "dj_route_status_buffer", "dj_route_return", "dj_route_statuses",
-           "dj_measure_copy"]
+           "dj_measure_copy", "dj_route_agree", "dj_router_get_limits"]
 # include/dj_batcher.h
-BATCHER_SYMBOLS = ["dj_batcher_create", "dj_batcher_destroy", "dj_batcher_set_clock", "dj_batcher_join",
+BATCHER_SYMBOLS = ["dj_batcher_create", "dj_batcher_create_routed", "dj_batcher_destroy", "dj_batcher_set_clock", "dj_batcher_join",
                    "dj_batcher_fork", "dj_batcher_join_wait", "dj_batcher_fork_wait", "dj_batcher_run",
                    "dj_batcher_get_stats"]
 STATUS_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int32)
@@ -211,8 +211,14 @@ def load():
         L.dj_route_return.argtypes = [vp, ctypes.c_int]
         L.dj_route_statuses.restype = i32
         L.dj_route_statuses.argtypes = [vp, ctypes.c_int, vp, vp]
+        L.dj_route_agree.restype = i32
+        L.dj_route_agree.argtypes = [vp, u32, vp]
+        L.dj_router_get_limits.restype = i32
+        L.dj_router_get_limits.argtypes = [vp, vp, vp, vp, vp, vp]
     L.dj_batcher_create.restype = i32
     L.dj_batcher_create.argtypes = [vp, ctypes.POINTER(BatcherConfig), ctypes.POINTER(vp)]
+    L.dj_batcher_create_routed.restype = i32
+    L.dj_batcher_create_routed.argtypes = [vp, vp, ctypes.POINTER(BatcherConfig), ctypes.POINTER(vp)]
     L.dj_batcher_destroy.restype = None
     L.dj_batcher_destroy.argtypes = [vp]
     L.dj_batcher_set_clock.restype = i32

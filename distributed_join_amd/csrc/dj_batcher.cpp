@@ -12,6 +12,14 @@
 // id" keeps that order although the engine applies forks and joins as separate batches.  Requests of
 // different lanes that were staged in the same window are concurrent requests: any interleaving is a valid
 // serialisation.  A request staged after another one was ANSWERED is applied in a later window.
+//
+// Routed form (dj_batcher_create_routed): the batcher of one rank of a node whose barriers are sharded over several
+// engines.  Its windows are exchanged through the rank's dj_router: every rank's drain thread runs the same CYCLES —
+// agree (one word per rank: batches of forks, batches of joins, "I want to stop"), then that many routed fork batches,
+// then that many routed join batches, each applied piece by piece on the owners' engines with the statuses returned
+// to the submitting rank (dj_route_return / dj_route_statuses) and handed to the callers that wait for them.  A window
+// has ONE phase there (forks, then joins): a fork that would have to follow a staged join of its barrier waits for the
+// next window instead of cutting a phase, so that every rank makes the same number of exchanges per cycle.
 #include <hip/hip_runtime.h>
 
 #include <atomic>
@@ -137,6 +145,8 @@ struct dj_batcher {
     int32_t* h_status = nullptr;     // pinned, max_batch
     dj_batcher_stats stats{};
     int fatal = 0;                   // first engine error seen by the drain thread; answers carry it as status
+    dj_router* router = nullptr;     // routed form: this rank's router (d_status then holds the answers that came home)
+    uint32_t world = 1;
 };
 
 namespace {
@@ -332,9 +342,181 @@ void drain_loop(dj_batcher* b) {
     }
 }
 
+// ---- routed form ---------------------------------------------------------------------------------------------------
+constexpr uint32_t AGREE_STOP = 1u << 31, AGREE_MASK = 0xFFFu;      // word: fork batches | join batches << 12 | stop
+
+// One routed batch of this cycle (a collective: every rank calls it, with n = 0 when it has nothing of that kind):
+// the first n rows of the pinned staging go to their owners, this rank's engine applies what it owns, and the first n
+// answers in b->h_status are this rank's own requests' statuses.
+int routed_exchange(dj_batcher* b, bool forks, uint32_t n, uint64_t now) {
+    hipStream_t st = static_cast<hipStream_t>(dj_stream(b->e));
+    if (n) {
+        if (forks) {
+            if (!hip_ok(hipMemcpyAsync(b->d_frecs, b->h_frecs, (size_t)n * sizeof(dj_fork_rec), hipMemcpyHostToDevice, st))) return DJ_E_HIP;
+        } else {
+            if (!hip_ok(hipMemcpyAsync(b->d_jrecs, b->h_jrecs, (size_t)n * sizeof(dj_join_rec), hipMemcpyHostToDevice, st))) return DJ_E_HIP;
+            if (!hip_ok(hipMemcpyAsync(b->d_jpay, b->h_jpay, (size_t)n * b->pitch, hipMemcpyHostToDevice, st))) return DJ_E_HIP;
+        }
+        if (!hip_ok(hipStreamSynchronize(st))) return DJ_E_HIP;      // the partition reads them on the router's stream
+    }
+    int h = -1;
+    int rc = dj_route_start(b->router, n, forks ? reinterpret_cast<const dj_join_rec*>(b->d_frecs) : b->d_jrecs, forks ? nullptr : b->d_jpay, &h);
+    int more = 1;
+    while (rc == DJ_OK && more) {
+        const dj_join_rec* pr = nullptr;
+        const uint8_t* pp = nullptr;
+        uint32_t pn = 0;
+        int32_t* d_st = nullptr;
+        rc = dj_route_next(b->router, h, &pr, &pp, &pn, &more);
+        if (rc == DJ_OK) rc = dj_route_status_buffer(b->router, h, &d_st);
+        if (rc == DJ_OK) rc = forks ? dj_fork_batch(b->e, pn, reinterpret_cast<const dj_fork_rec*>(pr), d_st)
+                                    : dj_join_batch(b->e, pn, pr, pp, b->pitch, now, d_st);
+        if (rc == DJ_OK) rc = dj_route_return(b->router, h);
+    }
+    if (rc == DJ_OK) rc = dj_route_statuses(b->router, h, b->d_status, st);
+    if (rc == DJ_OK) rc = dj_route_release(b->router, h);
+    if (rc == DJ_OK && n && !hip_ok(hipMemcpyAsync(b->h_status, b->d_status, (size_t)n * 4, hipMemcpyDeviceToHost, st))) rc = DJ_E_HIP;
+    if (rc == DJ_OK) rc = dj_sync(b->e);
+    return rc;
+}
+
+void drain_loop_routed(dj_batcher* b) {
+    (void)hipSetDevice(b->ecfg.device);
+    std::vector<Waiter*> waiters;
+    std::vector<Task> tasks;
+    std::vector<uint32_t> words(b->world);
+    const uint32_t mb = b->cfg.max_batch;
+    // how long a rank with nothing to do sleeps before it joins the next agreement: its peers' requests wait that long
+    const uint32_t idle_us = b->cfg.max_wait_us ? b->cfg.max_wait_us : 100;
+    auto any_staged = [&] {
+        for (Lane& l : b->lanes) {
+            std::lock_guard<std::mutex> g(l.mu);
+            if (!l.side[l.fill].empty()) return true;
+        }
+        return false;
+    };
+    for (;;) {
+        bool staged = any_staged(), want_stop = false;
+        {
+            std::unique_lock<std::mutex> lk(b->mu);
+            if (!staged && b->tasks.empty() && !b->stop) {
+                b->sleeping.store(true, std::memory_order_seq_cst);
+                lk.unlock();
+                staged = any_staged();
+                lk.lock();
+                if (!staged) b->cv_work.wait_for(lk, std::chrono::microseconds(idle_us), [&] { return b->poked || !b->tasks.empty() || b->stop; });
+                b->sleeping.store(false, std::memory_order_seq_cst);
+            } else if (staged && b->tasks.empty() && !b->stop && b->cfg.max_wait_us) {
+                b->sleeping.store(true, std::memory_order_seq_cst);
+                b->cv_work.wait_for(lk, std::chrono::microseconds(b->cfg.max_wait_us), [&] { return b->lane_full || !b->tasks.empty() || b->stop; });
+                b->sleeping.store(false, std::memory_order_seq_cst);
+            }
+            b->poked = b->lane_full = false;
+            tasks.swap(b->tasks);
+            want_stop = b->stop;
+        }
+        Window w;
+        for (Lane& l : b->lanes) {
+            std::unique_lock<std::mutex> g(l.mu);
+            LaneSide& s = l.side[l.fill];
+            if (s.empty()) continue;
+            l.fill ^= 1;
+            g.unlock();
+            l.cv_space.notify_all();
+            w.side[w.n++] = &s;
+            w.forks += s.frecs.size();
+            w.joins += s.jrecs.size();
+        }
+        uint64_t (*clock_fn)(void*);
+        void* clock_user;
+        {
+            std::lock_guard<std::mutex> g(b->mu);
+            clock_fn = b->clock_fn;
+            clock_user = b->clock_user;
+        }
+        const uint64_t now = clock_fn(clock_user);
+        // the agreement: what every rank brings to this cycle
+        const uint32_t fc = (uint32_t)((w.forks + mb - 1) / mb), jc = (uint32_t)((w.joins + mb - 1) / mb);
+        const bool idle = w.n == 0 && tasks.empty();
+        int rc = b->fatal;
+        if (rc == DJ_OK) rc = dj_route_agree(b->router, (fc & AGREE_MASK) | ((jc & AGREE_MASK) << 12) | (want_stop && idle ? AGREE_STOP : 0u), words.data());
+        uint32_t FC = 0, JC = 0;
+        bool all_stop = rc == DJ_OK;
+        if (rc == DJ_OK)
+            for (uint32_t x : words) {
+                if ((x & AGREE_MASK) > FC) FC = x & AGREE_MASK;
+                if (((x >> 12) & AGREE_MASK) > JC) JC = (x >> 12) & AGREE_MASK;
+                if (!(x & AGREE_STOP)) all_stop = false;
+            }
+        waiters.clear();
+        uint64_t largest = 0, calls = 0;
+        // forks, then joins: batch c takes this rank's next mb rows of that kind in lane order (none when it has run out:
+        // the exchange is a collective all the same)
+        for (int kind = 0; kind < 2; ++kind) {
+            const bool forks = kind == 0;
+            int k = 0;
+            size_t i = 0;
+            const uint32_t batches = forks ? FC : JC, mine = forks ? fc : jc;
+            for (uint32_t c = 0; c < (rc == DJ_OK ? batches : mine); ++c) {
+                uint32_t n = 0;
+                for (; k < w.n && n < mb; ++k, i = 0) {
+                    LaneSide& s = *w.side[k];
+                    const size_t total = forks ? s.frecs.size() : s.jrecs.size();
+                    for (; i < total && n < mb; ++i, ++n) {
+                        if (forks) {
+                            b->h_frecs[n] = s.frecs[i];
+                            b->ans[n] = s.fans[i];
+                        } else {
+                            b->h_jrecs[n] = s.jrecs[i];
+                            if (s.jrecs[i].len) memcpy(b->h_jpay + (size_t)n * b->pitch, s.bytes.data() + s.joff[i], s.jrecs[i].len);
+                            b->ans[n] = s.jans[i];
+                        }
+                        if (b->ans[n].cb == wait_cb) waiters.push_back(static_cast<Waiter*>(b->ans[n].user));
+                    }
+                    if (i < total) break;          // the batch is full in the middle of this lane
+                }
+                if (rc == DJ_OK) rc = routed_exchange(b, forks, n, now);
+                answer_all(b, n, rc);
+                if (n > largest) largest = n;
+                if (n) ++calls;
+            }
+        }
+        if (rc != DJ_OK && !b->fatal) b->fatal = rc;
+        for (int k = 0; k < w.n; ++k) w.side[k]->clear();
+        for (Task& t : tasks) t.w->status = t.fn(t.user, b->e, now);
+        {
+            std::lock_guard<std::mutex> g(b->mu);
+            if (w.forks || w.joins) {
+                b->stats.batches += calls;
+                b->stats.forks += w.forks;
+                b->stats.joins += w.joins;
+                if (largest > b->stats.largest_batch) b->stats.largest_batch = largest;
+            }
+            for (Waiter* x : waiters) x->done = true;
+            for (Task& t : tasks) t.w->done = true;
+            b->stats.tasks += tasks.size();
+        }
+        if (!waiters.empty() || !tasks.empty()) b->cv_done.notify_all();
+        tasks.clear();
+        if (all_stop) return;                          // every rank read the same words: they all leave after this cycle
+        if (rc != DJ_OK && want_stop && idle) return;  // the exchange is broken: nothing left to agree on
+    }
+}
+
 }  // namespace
 
+static int batcher_create(dj_engine* e, dj_router* router, const dj_batcher_config* cfg, dj_batcher** out);
+
 extern "C" int dj_batcher_create(dj_engine* e, const dj_batcher_config* cfg, dj_batcher** out) {
+    return batcher_create(e, nullptr, cfg, out);
+}
+
+extern "C" int dj_batcher_create_routed(dj_engine* e, dj_router* router, const dj_batcher_config* cfg, dj_batcher** out) {
+    if (!router) return DJ_E_INVALID;
+    return batcher_create(e, router, cfg, out);
+}
+
+static int batcher_create(dj_engine* e, dj_router* router, const dj_batcher_config* cfg, dj_batcher** out) {
     if (!e || !cfg || !out || cfg->struct_size != sizeof(dj_batcher_config)) return DJ_E_INVALID;
     dj_config ec;
     if (dj_get_config(e, &ec) != DJ_OK) return DJ_E_INVALID;
@@ -346,6 +528,18 @@ extern "C" int dj_batcher_create(dj_engine* e, const dj_batcher_config* cfg, dj_
     b->cfg = *cfg;
     b->ecfg = ec;
     b->pitch = ((uint64_t)(cfg->max_message ? cfg->max_message : 1) + 15) / 16 * 16;
+    if (router) {
+        // the router moves rows of its own pitch and hands out pieces of up to max_recv rows, which the engine must take
+        uint32_t world = 0, max_send = 0, max_recv = 0;
+        uint64_t rpitch = 0;
+        if (dj_router_get_limits(router, &world, nullptr, &max_send, &max_recv, &rpitch) != DJ_OK || rpitch != b->pitch ||
+            max_send < cfg->max_batch || max_recv > ec.max_batch || world < 1) {
+            delete b;
+            return DJ_E_INVALID;
+        }
+        b->router = router;
+        b->world = world;
+    }
     const size_t mb = cfg->max_batch;
     bool ok = hip_ok(hipSetDevice(ec.device));
     ok = ok && hip_ok(hipHostMalloc((void**)&b->h_jrecs, mb * sizeof(dj_join_rec), hipHostMallocDefault));
@@ -361,7 +555,7 @@ extern "C" int dj_batcher_create(dj_engine* e, const dj_batcher_config* cfg, dj_
         dj_batcher_destroy(b);
         return DJ_E_NOMEM;
     }
-    b->th = std::thread(drain_loop, b);
+    b->th = router ? std::thread(drain_loop_routed, b) : std::thread(drain_loop, b);
     *out = b;
     return DJ_OK;
 }
@@ -436,12 +630,17 @@ extern "C" int dj_batcher_fork(dj_batcher* b, const dj_fork_rec* rec, dj_status_
     if (!b || !rec || !cb) return DJ_E_INVALID;
     Lane& l = my_lane(b);
     std::unique_lock<std::mutex> lk(l.mu);
-    while (l.side[l.fill].frecs.size() >= b->cfg.max_batch) {
+    // (routed form: a window has one phase, so a fork behind a staged join of its barrier waits for the next window)
+    auto must_wait = [&] {
+        const LaneSide& f = l.side[l.fill];
+        return f.frecs.size() >= b->cfg.max_batch || (b->router && f.set_has(rec->fp_lo));
+    };
+    while (must_wait()) {
         lk.unlock();
         if (stopping(b)) return DJ_E_INVALID;
         poke(b, true);
         lk.lock();
-        l.cv_space.wait_for(lk, std::chrono::milliseconds(1), [&] { return l.side[l.fill].frecs.size() < b->cfg.max_batch; });
+        l.cv_space.wait_for(lk, std::chrono::milliseconds(1), [&] { return !must_wait(); });
     }
     LaneSide& s = l.side[l.fill];
     const bool was_empty = s.empty();

@@ -149,6 +149,9 @@ struct dj_router {
     // the partition's time on one stream with it), and the engine's own stream that applies what arrived.
     hipStream_t stream = nullptr, comm_stream = nullptr, engine_stream = nullptr;
     Set sets[MAX_DEPTH];
+    uint32_t* agree_d = nullptr;      // [1 + MAX_RANKS] this rank's word, then everybody's (dj_route_agree)
+    uint32_t* agree_h = nullptr;      // pinned copy of everybody's
+    hipEvent_t agree_ev = nullptr;
     std::string err;
     std::mutex mu;
 };
@@ -207,6 +210,9 @@ extern "C" void dj_router_destroy(dj_router* r) {
         if (s.ready) (void)hipEventDestroy(s.ready);
         if (s.freed) (void)hipEventDestroy(s.freed);
     }
+    (void)hipFree(r->agree_d);
+    if (r->agree_h) (void)hipHostFree(r->agree_h);
+    if (r->agree_ev) (void)hipEventDestroy(r->agree_ev);
     if (r->comm) (void)g_rccl.CommDestroy(r->comm);
     if (r->stream) (void)hipStreamDestroy(r->stream);
     if (r->comm_stream) (void)hipStreamDestroy(r->comm_stream);
@@ -254,6 +260,9 @@ extern "C" int dj_router_create(dj_engine* e, uint32_t n_ranks, uint32_t rank, c
             R_HIP(nullptr, hipEventCreateWithFlags(&s.ready, hipEventDisableTiming));
             R_HIP(nullptr, hipEventCreateWithFlags(&s.freed, hipEventDisableTiming));
         }
+        R_HIP(nullptr, hipMalloc((void**)&r->agree_d, (1 + MAX_RANKS) * 4));
+        R_HIP(nullptr, hipHostMalloc((void**)&r->agree_h, (1 + MAX_RANKS) * 4, hipHostMallocDefault));
+        R_HIP(nullptr, hipEventCreateWithFlags(&r->agree_ev, hipEventDisableTiming));
         ncclUniqueId id;
         memcpy(&id, id128, 128);
         R_NCCL(nullptr, g_rccl.CommInitRank(&r->comm, r->world, id, r->rank));
@@ -486,5 +495,30 @@ extern "C" int dj_route_statuses(dj_router* r, int handle, int32_t* d_status_out
     s.home_pending = true;
     if (stream) R_HIP(r, hipStreamWaitEvent((hipStream_t)stream, s.home, 0));
     else R_HIP(r, hipEventSynchronize(s.home));
+    return DJ_OK;
+}
+
+// ---- small agreements between the ranks' hosts ---------------------------------------------------------------------
+extern "C" int dj_route_agree(dj_router* r, uint32_t word, uint32_t* h_words) {
+    if (!r || !h_words) return DJ_E_INVALID;
+    std::lock_guard<std::mutex> g(r->mu);
+    R_HIP(r, hipSetDevice(r->cfg.device));
+    r->agree_h[0] = word;
+    R_HIP(r, hipMemcpyAsync(r->agree_d, r->agree_h, 4, hipMemcpyHostToDevice, r->comm_stream));
+    R_NCCL(r, g_rccl.AllGather(r->agree_d, r->agree_d + 1, 1, ncclUint32, r->comm, r->comm_stream));
+    R_HIP(r, hipMemcpyAsync(r->agree_h + 1, r->agree_d + 1, (size_t)r->world * 4, hipMemcpyDeviceToHost, r->comm_stream));
+    R_HIP(r, hipEventRecord(r->agree_ev, r->comm_stream));
+    R_HIP(r, hipEventSynchronize(r->agree_ev));
+    memcpy(h_words, r->agree_h + 1, (size_t)r->world * 4);
+    return DJ_OK;
+}
+
+extern "C" int dj_router_get_limits(const dj_router* r, uint32_t* n_ranks, uint32_t* rank, uint32_t* max_send, uint32_t* max_recv, uint64_t* pitch) {
+    if (!r) return DJ_E_INVALID;
+    if (n_ranks) *n_ranks = (uint32_t)r->world;
+    if (rank) *rank = (uint32_t)r->rank;
+    if (max_send) *max_send = r->max_send;
+    if (max_recv) *max_recv = r->max_recv;
+    if (pitch) *pitch = r->pitch;
     return DJ_OK;
 }

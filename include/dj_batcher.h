@@ -50,6 +50,21 @@ typedef struct dj_batcher_stats {
  * points serialise themselves), but such a call lands between any two calls of the drain thread,
  * e.g. between the forks and the joins of one batch; dj_batcher_run() places it between two batches. */
 int dj_batcher_create(dj_engine* e, const dj_batcher_config* cfg, dj_batcher** out);
+/* The batcher of ONE RANK of a node whose barriers are sharded over several engines (one engine = one GPU, owner =
+ * dj_owner_of): requests enter at any rank, the rank's windows are exchanged through its router (dj_router_create,
+ * include/dj_engine.h), the owner's engine applies every record, and the record's status returns to the rank that
+ * holds the request (dj_route_return / dj_route_statuses) and to the caller's callback — what the reference's handlers
+ * answer per request (ring.clj:54-69; 404 / 400 redis.clj:152-153,159) whichever replica took it.  Every rank of the
+ * router's communicator creates one; their drain threads then run the same cycles: an agreement (dj_route_agree: how many
+ * batches of forks and of joins each rank has staged, whether all want to stop), then as many routed fork batches and
+ * routed join batches as the busiest rank has, empty ones where a rank has run out.  A rank with nothing staged joins
+ * the next agreement after max_wait_us (100 us when that is 0): a request waits at most that long for idle peers.
+ * Requirements: router pitch = max_message rounded up to 16 (1 -> 16), router max_send >= max_batch, the engine's
+ * max_batch >= the router's max_recv.  dj_batcher_destroy is a collective here: a rank's drain thread leaves only when
+ * every rank has been asked to stop and has nothing staged.  Everything else (dj_batcher_join / _fork / _run, the
+ * clock) works as on a plain batcher; dj_batcher_run runs on this rank's engine (sweeps, acks and recovers are
+ * GPU-local). */
+int dj_batcher_create_routed(dj_engine* e, dj_router* router, const dj_batcher_config* cfg, dj_batcher** out);
 /* Applies what is still queued, answers it, stops the thread. */
 void dj_batcher_destroy(dj_batcher* b);
 

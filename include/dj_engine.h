@@ -474,6 +474,14 @@ int  dj_route_status_buffer(dj_router* r, int handle, int32_t** d_status_piece);
 int  dj_route_return(dj_router* r, int handle);
 int  dj_route_statuses(dj_router* r, int handle, int32_t* d_status_out, void* stream);
 
+
+/* One word from every rank to every rank's host: h_words[s] = the word rank s passed (n_ranks entries).  A collective
+ * that waits: the hosts of a node use it to agree on what the next exchanges are (how many batches each has staged,
+ * whether all want to stop) before any of them enters one — see dj_batcher_create_routed in dj_batcher.h. */
+int  dj_route_agree(dj_router* r, uint32_t word, uint32_t* h_words);
+/* What the router was created with (any pointer may be NULL). */
+int  dj_router_get_limits(const dj_router* r, uint32_t* n_ranks, uint32_t* rank, uint32_t* max_send, uint32_t* max_recv, uint64_t* pitch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -10,8 +10,8 @@
 // Semantics kept: ncclAllGather is a collective in call order per communicator; ncclSend / ncclRecv inside one
 // ncclGroupStart/End pair match by (source, destination) in issue order, a group with no operation is a no-op, and
 // nothing blocks before ncclGroupEnd.  Everything is done synchronously at the call (the caller's stream is drained
-// first, the bytes are moved with blocking device-to-device copies), which is a legal if slow execution of calls that
-// RCCL would merely queue on the stream.
+// first, the bytes are moved with device-to-device copies on that stream, which are waited for), which is a legal if slow
+// execution of calls that RCCL would merely queue on the stream.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -78,7 +78,10 @@ ncclResult_t run(std::vector<Op>& ops) {
             q.pop_front();
         }
         if (p->bytes != o.bytes) return ncclInvalidArgument;          // the two sides planned different pieces
-        if (hipMemcpy(o.rbuf, p->buf, o.bytes, hipMemcpyDeviceToDevice) != hipSuccess) return ncclUnhandledCudaError;
+        // on the caller's stream, then waited for: a device-to-device hipMemcpy may return before the bytes have moved, and
+        // it runs on the null stream, which the router's and the engine's non-blocking streams do not wait for
+        if (hipMemcpyAsync(o.rbuf, p->buf, o.bytes, hipMemcpyDeviceToDevice, o.stream) != hipSuccess ||
+            hipStreamSynchronize(o.stream) != hipSuccess) return ncclUnhandledCudaError;
         {
             std::lock_guard<std::mutex> g(w->mu);
             p->taken = true;
@@ -157,8 +160,9 @@ ncclResult_t ncclAllGather(const void* send, void* recv, size_t count, ncclDataT
         all = w->gathers[call];
     }
     for (int r = 0; r < w->n; ++r)
-        if (hipMemcpy(static_cast<char*>(recv) + (size_t)r * bytes, all[r], bytes, hipMemcpyDeviceToDevice) != hipSuccess)
+        if (hipMemcpyAsync(static_cast<char*>(recv) + (size_t)r * bytes, all[r], bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess)
             return ncclUnhandledCudaError;
+    if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
     std::unique_lock<std::mutex> lk(w->mu);
     ++w->gathers_read[call];
     w->cv.notify_all();

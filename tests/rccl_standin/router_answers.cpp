@@ -150,6 +150,14 @@ int main(int argc, char** argv) {
                     DJ_OK_(dj_route_status_buffer(rt, h, &d_st), rt);
                     if (fork) DJ_OK_(dj_fork_batch(e, pn, (const dj_fork_rec*)pr, d_st), rt);
                     else DJ_OK_(dj_join_batch(e, pn, pr, pp, PITCH, now, d_st), rt);
+                    if (getenv("DJ_TEST_DEBUG") && fork) {          // what did the owner's engine answer, and to which record
+                        HIP_OK(hipStreamSynchronize(es));
+                        std::vector<int32_t> st(pn);
+                        std::vector<dj_fork_rec> rr(pn);
+                        if (pn) { HIP_OK(hipMemcpy(st.data(), d_st, (size_t)pn * 4, hipMemcpyDeviceToHost)); HIP_OK(hipMemcpy(rr.data(), pr, (size_t)pn * 32, hipMemcpyDeviceToHost)); }
+                        for (uint32_t k = 0; k < pn; ++k)
+                            if (st[k] != DJ_FORK_CREATED) { fprintf(stderr, "owner %d: fork row %u of %u answered %d: count %u fp %llx\n", r, k, pn, st[k], rr[k].count, (unsigned long long)rr[k].fp_lo); break; }
+                    }
                     DJ_OK_(dj_route_return(rt, h), rt);
                     ++rounds;
                 }

@@ -43,3 +43,19 @@ def test_native_router_brings_every_answer_home(ranks, nb, n, max_recv, hot):
     assert "every rank got one store's answers" in p.stdout
     rounds = int(p.stdout.split("due at the end,")[-1].split("rounds")[0])
     assert (rounds > 1) == (hot > 0), p.stdout
+
+
+@pytest.mark.parametrize("ranks,threads,barriers", [(2, 4, 600), (8, 2, 800)])
+def test_node_front_answers_every_blocking_caller(ranks, threads, barriers):
+    """The per-request front of a sharded node (dj_batcher_create_routed; tests/rccl_standin/node_front.cpp): request
+    threads on every rank call dj_batcher_fork_wait / dj_batcher_join_wait for barriers owned by any rank and each gets
+    the answer one oracle store gives for its barrier's request sequence (404 before the fork, 201, WAITING / COMPLETE,
+    400, replays, re-forks); a barrier joined by all threads at once completes exactly once; the ranks' publishers
+    together pop what the one store pops."""
+    exe, lib = os.path.join(DIR, "node_front"), os.path.join(DIR, "librccl.so.1")
+    assert os.path.exists(exe) and os.path.exists(lib), "run __graft_entry__.build() first"
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = DIR + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    p = subprocess.run([exe, str(ranks), str(threads), str(barriers)], env=env, capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "every caller got one store's answer" in p.stdout
