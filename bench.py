@@ -481,6 +481,7 @@ def main():
         # step numbers go on from the warm-up's (whole jobs): a barrier forked once stays forked once
         step(warm + k, prefetch=min(2, timed_steps - 1 - k))
     ev1.record(es)
+    issue = time.perf_counter() - t0      # when the host had queued the last step: close to `wall` = the host is the limit
     barrier()
     wall = time.perf_counter() - t0
     elapsed = torch.tensor([wall], dtype=torch.float64, device=dev)
@@ -603,7 +604,7 @@ def main():
                                    + (" (REHEARSAL: all ranks on one GPU, gloo)" if a.rehearse_on_one_gpu else "")},
             "continuations_per_s": float(fired.item()) / elapsed_s,
             "continuations_fired": int(fired.item()),
-            "gpu_stream_ms": gpu_ms,
+            "gpu_stream_ms": gpu_ms, "host_issue_ms_per_step": issue * 1e3 / timed_steps,
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "config3": c3,
         }
         print(json.dumps(out))

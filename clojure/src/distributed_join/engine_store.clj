@@ -92,20 +92,74 @@
     (.setInt 44 (int max-message-bytes))
     (.setLong 48 (long (:check-publish-delay-ms env)))))               ; config.edn:16
 
-(defonce engine
-  (delay (let [ref (PointerByReference.)]
-           (check (native-int dj "dj_create" (make-config) ref) "dj_create")
-           (.getValue ref))))
+(def engine-ranks
+  "Engines of this node (one per GPU, device ordinals 0 .. n-1).  With more than one, barriers shard by fingerprint
+  (dj_owner_of), every rank has a router and a ROUTED batcher (dj_batcher_create_routed), a request enters at the
+  batcher of any rank and its answer comes back to the thread that waits for it; single-key commands go to the
+  owner's engine directly, the publisher polls every rank.  (Like everything in this file: written against the
+  C ABI, never compiled here.)"
+  (long (or (:engine-ranks env) 1)))
 
-(defonce batcher
-  (delay (let [cfg (doto (Memory. 16)                                  ; struct dj_batcher_config
-                     (.setInt 0 (int 16))
-                     (.setInt 4 (int (or (:engine-batcher-max-batch env) 65536)))
-                     (.setInt 8 (int (or (:engine-batcher-linger-us env) 0)))
-                     (.setInt 12 (int max-message-bytes)))
-               ref (PointerByReference.)]
-           (check (native-int dj "dj_batcher_create" @engine cfg ref) "dj_batcher_create")
-           (.getValue ref))))
+(defn- create-engine [device]
+  (let [ref (PointerByReference.)]
+    (check (native-int dj "dj_create" (doto (make-config) (.setInt 4 (int device))) ref) "dj_create")
+    (.getValue ref)))
+
+(defn- batcher-config ^Memory []
+  (doto (Memory. 16)                                                   ; struct dj_batcher_config
+    (.setInt 0 (int 16))
+    (.setInt 4 (int (or (:engine-batcher-max-batch env) 65536)))
+    (.setInt 8 (int (or (:engine-batcher-linger-us env) 0)))
+    (.setInt 12 (int max-message-bytes))))
+
+(defonce node
+  ;; a vector of {:device d :engine e :router r :batcher b}, one per rank; router nil with a single rank
+  (delay
+    (if (= engine-ranks 1)
+      (let [e (create-engine (or (:engine-device env) 0))
+            ref (PointerByReference.)]
+        (check (native-int dj "dj_batcher_create" e (batcher-config) ref) "dj_batcher_create")
+        [{:device (or (:engine-device env) 0) :engine e :router nil :batcher (.getValue ref)}])
+      (let [engines (mapv create-engine (range engine-ranks))
+            id (Memory. 128)
+            pitch (long (* 16 (quot (+ (max max-message-bytes 1) 15) 16)))      ; the batcher's staging rows
+            batch (int (or (:engine-batcher-max-batch env) 65536))
+            _ (check (native-int dj "dj_route_unique_id" id) "dj_route_unique_id")
+            ;; dj_router_create is a collective over the ranks: one thread per rank
+            routers (->> (range engine-ranks)
+                         (mapv (fn [r] (future
+                                         (let [ref (PointerByReference.)]
+                                           (check (native-int dj "dj_router_create" (nth engines r) (int engine-ranks) (int r) id
+                                                              batch (int (or (:engine-max-batch env) (bit-shift-left 1 20)))
+                                                              (long pitch) (int 3) ref)
+                                                  "dj_router_create")
+                                           (.getValue ref)))))
+                         (mapv deref))]
+        (mapv (fn [r]
+                (let [ref (PointerByReference.)]
+                  (check (native-int dj "dj_batcher_create_routed" (nth engines r) (nth routers r) (batcher-config) ref)
+                         "dj_batcher_create_routed")
+                  {:device r :engine (nth engines r) :router (nth routers r) :batcher (.getValue ref)}))
+              (range engine-ranks))))))
+
+(defonce engine (delay (:engine (first @node))))      ; the one engine of a single-rank node
+(defonce batcher (delay (:batcher (first @node))))
+
+(defn owner-rank [[lo hi]]
+  (if (= engine-ranks 1)
+    0
+    (.invokeInt ^Function (.getFunction dj "dj_owner_of") (to-array [(long lo) (long hi) (int engine-ranks)]))))
+
+(defn engine-of
+  "The engine that holds the barrier with this fingerprint (single-key commands go there directly)."
+  [fp]
+  (:engine (nth @node (owner-rank fp))))
+
+(defn request-batcher
+  "The batcher a request thread stages its request in: any rank's will do (the routed batchers bring the answer
+  back); threads are spread over the ranks by their id."
+  []
+  (:batcher (nth @node (mod (.getId (Thread/currentThread)) engine-ranks))))
 
 ;; device buffers of the publisher (one sweep / ack / recover at a time: the two scheduler threads of
 ;; ring.clj:113-114 take this lock around their poll)
@@ -150,7 +204,7 @@
                 (.setLong 24 (long (:timeout-secs record))))
           status (Memory. 4)
           previous (.put forks fp (assoc record :barrier-id barrier-id))]   ; before the engine can pop it
-      (check (native-int dj "dj_batcher_fork_wait" @batcher rec status) "dj_batcher_fork_wait")
+      (check (native-int dj "dj_batcher_fork_wait" (request-batcher) rec status) "dj_batcher_fork_wait")
       (if (= 1 (.getInt status 0))                                     ; DJ_FORK_CREATED
         barrier-id
         (do (if previous (.put forks fp previous) (.remove forks fp))    ; a refused fork leaves the barrier as it was
@@ -171,7 +225,7 @@
                 (.setInt 24 (int (or (:max-wait record) 0)))
                 (.setInt 28 (int 0)))
           status (Memory. 4)]
-      (check (native-int dj "dj_batcher_join_wait" @batcher rec message status) "dj_batcher_join_wait")
+      (check (native-int dj "dj_batcher_join_wait" (request-batcher) rec message status) "dj_batcher_join_wait")
       (.getInt status 0))))
 
 (defn join-status
@@ -242,13 +296,16 @@
              lens (Memory. (* 4 max-count))
              waits (Memory. (* 4 max-count))
              payloads (Memory. (* payload-stride max-count))]
-         (check (native-int dj "dj_snapshot_one" @engine (long lo) (long hi) (int (if update-ts? 1 0)) meta lens waits payloads)
+         (check (native-int dj "dj_snapshot_one" (engine-of fp) (long lo) (long hi) (int (if update-ts? 1 0)) meta lens waits payloads)
                 "dj_snapshot_one")
          (when (zero? (bit-and 2 (.getInt meta 36)))                    ; DJ_CONT_NO_METADATA
            {:metadata (metadata-of fp meta)
             :joins    (read-messages barrier-id lens waits payloads 0 (.getInt meta 32))}))))))
 
 ;; ---- publisher -------------------------------------------------------------------------------------
+;; sweep / ack / recover below work on ONE engine (@engine, rank 0 of the node; its device buffers are `buffers`).
+;; With :engine-ranks above 1 every rank needs its own publisher loop over its own engine and buffers (sweeps, acks and
+;; recovers are GPU-local): run these three with `engine` and `buffers` rebound per rank — not written out here.
 
 (defn sweep
   "One poll of the publisher (core.clj:180-188 up to the POST).  Deferred of a vector of
@@ -339,16 +396,21 @@
   "redis/get-publish-date (redis.clj:295-297): the primary-queue score, nil when not queued."
   [barrier-id]
   (deferred/future
-    (let [[lo hi] (fingerprint barrier-id) out (Memory. 16)]
-      (check (native-int dj "dj_queue_scores" @engine (long lo) (long hi) out (.share out 8)) "dj_queue_scores")
+    (let [[lo hi :as fp] (fingerprint barrier-id) out (Memory. 16)]
+      (check (native-int dj "dj_queue_scores" (engine-of fp) (long lo) (long hi) out (.share out 8)) "dj_queue_scores")
       (let [at (.getLong out 0)]
         (when-not (= at -1) at)))))                                    ; DJ_NOT_QUEUED
 
 (defn shutdown []                                                       ; redis/shutdown, redis.clj:299-300
   (log/info "Shutting down the barrier engine...")
-  (when (realized? batcher)
-    (.invokeVoid ^Function (.getFunction dj "dj_batcher_destroy") (to-array [@batcher])))
-  (when (realized? engine)
-    (when-let [path (:engine-checkpoint-path env)]
-      (check (native-int dj "dj_checkpoint_save" @engine ^String path) "dj_checkpoint_save"))
-    (.invokeVoid ^Function (.getFunction dj "dj_destroy") (to-array [@engine]))))
+  (when (realized? node)
+    ;; a routed batcher's destroy is a collective (its drain thread leaves when every rank has been asked to stop)
+    (->> @node
+         (mapv (fn [{:keys [batcher]}] (future (.invokeVoid ^Function (.getFunction dj "dj_batcher_destroy") (to-array [batcher])))))
+         (run! deref))
+    (doseq [{:keys [router]} @node :when router]
+      (.invokeVoid ^Function (.getFunction dj "dj_router_destroy") (to-array [router])))
+    (doseq [{:keys [engine device]} @node]
+      (when-let [path (:engine-checkpoint-path env)]
+        (check (native-int dj "dj_checkpoint_save" engine ^String (if (= engine-ranks 1) path (str path "." device))) "dj_checkpoint_save"))
+      (.invokeVoid ^Function (.getFunction dj "dj_destroy") (to-array [engine])))))

@@ -18,6 +18,11 @@
   would have produced and leave it as it is.  :count of join's answer is HLEN of the barrier's hash after the event
   (redis.clj:137,157), which the engine reports in the event's status word (dj_set_join_hlen).
 
+  With :engine-ranks above 1 (a node of several GPUs) requests go through the routed batchers of engine-store and the
+  single-key commands to the owner's engine (es/engine-of); all-publish-messages and
+  get-unprocessed-publish-messages below poll rank 0 only — a node needs them once per rank, with that rank's engine
+  and buffers (not written out: nothing here can be run).
+
   Id strings and the Fork maps (URLs) stay in this JVM, keyed by fingerprint; counts, deadlines, retry counters,
   messages and both queues live in HBM."
   (:require [clojure.tools.logging :as log]
@@ -65,7 +70,7 @@
                 (.setInt 40 (int (or (:publish-retry-cnt metadata) -1)))          ; DJ_NIL = key absent
                 (.setInt 44 (int (or (:timeout-publish-retry-cnt metadata) -1))))
           status (Memory. 4)]
-      (es/check (es/native-int es/dj "dj_update_metadata_one" @es/engine row status) "dj_update_metadata_one")
+      (es/check (es/native-int es/dj "dj_update_metadata_one" (es/engine-of fp) row status) "dj_update_metadata_one")
       (when-not (= 7 (.getInt status 0))                                 ; DJ_ACK_METADATA_SET
         (throw (ex-info "Database failure(s)" {:causes [(str "metadata refused: " (.getInt status 0))]})))
       (.put es/forks fp (-> metadata
@@ -77,7 +82,8 @@
 
 ;; redis/join answers HLEN (redis.clj:137,157): the engine puts it into every join's status word from here on
 (defonce ^:private hlen-on
-  (delay (es/check (es/native-int es/dj "dj_set_join_hlen" @es/engine (int 1)) "dj_set_join_hlen")))
+  (delay (doseq [{:keys [engine]} @es/node]
+           (es/check (es/native-int es/dj "dj_set_join_hlen" engine (int 1)) "dj_set_join_hlen"))))
 
 ;; redis.clj:143-159
 (defn join [record]
@@ -94,7 +100,7 @@
   (deferred/future
     (let [[lo hi :as fp] (es/fingerprint barrier-id)
           status (Memory. 4)]
-      (es/check (es/native-int es/dj "dj_complete_one" @es/engine (long lo) (long hi) status) "dj_complete_one")
+      (es/check (es/native-int es/dj "dj_complete_one" (es/engine-of fp) (long lo) (long hi) status) "dj_complete_one")
       (if (= 6 (.getInt status 0))                                       ; DJ_ACK_DIRTY
         (throw (ex-info "Join was updated before fork could be completed" {:updated-join-before-complete true}))
         (do (.remove es/forks fp) 1)))))
@@ -126,7 +132,7 @@
   (deferred/future
     (let [[lo hi :as fp] (es/fingerprint barrier-id)]
       (.putIfAbsent es/forks fp {:barrier-id barrier-id})                ; an id may be queued without metadata
-      (es/check (es/native-int es/dj "dj_store_in_publish_queue" @es/engine (long lo) (long hi) (long publish-at))
+      (es/check (es/native-int es/dj "dj_store_in_publish_queue" (es/engine-of fp) (long lo) (long hi) (long publish-at))
                 "dj_store_in_publish_queue")
       (list publish-at))))
 
@@ -134,9 +140,9 @@
 (defn store-nearest-in-publish-queue [barrier-id publish-at]
   (deferred/chain
     (deferred/future
-      (let [[lo hi] (es/fingerprint barrier-id)
+      (let [[lo hi :as fp] (es/fingerprint barrier-id)
             result (Memory. 4)]
-        (es/check (es/native-int es/dj "dj_store_nearest_in_publish_queue" @es/engine (long lo) (long hi)
+        (es/check (es/native-int es/dj "dj_store_nearest_in_publish_queue" (es/engine-of fp) (long lo) (long hi)
                                  (long publish-at) result)
                   "dj_store_nearest_in_publish_queue")
         (.getInt result 0)))

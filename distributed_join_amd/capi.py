@@ -75,7 +75,8 @@ SYMBOLS = ["dj_create", "dj_destroy", "dj_last_error", "dj_sync", "dj_stream", "
            "dj_router_last_error", "dj_route_start", "dj_route_advance", "dj_route_next", "dj_route_release",
            "dj_complete_one", "dj_update_metadata_one", "dj_store_nearest_in_publish_queue", "dj_unprocessed",
            "dj_set_join_hlen", "dj_scatter_statuses", "dj_route_status_buffer", "dj_route_return", "dj_route_statuses",
-           "dj_measure_copy", "dj_route_agree", "dj_router_get_limits"]
+           "dj_measure_copy", "dj_route_agree", "dj_router_get_limits",
+           "dj_partition_joins_self"]
 # include/dj_batcher.h
 BATCHER_SYMBOLS = ["dj_batcher_create", "dj_batcher_create_routed", "dj_batcher_destroy", "dj_batcher_set_clock", "dj_batcher_join",
                    "dj_batcher_fork", "dj_batcher_join_wait", "dj_batcher_fork_wait", "dj_batcher_run",
@@ -166,6 +167,9 @@ def load():
     L.dj_owner_of.argtypes = [u64, u64, u32]
     L.dj_partition_joins.restype = i32
     L.dj_partition_joins.argtypes = [vp, u32, u32, vp, vp, u64, vp, vp, vp, vp, vp]
+    if not os.environ.get("DJ_ENGINE_LIB") or hasattr(L, "dj_partition_joins_self"):
+        L.dj_partition_joins_self.restype = i32
+        L.dj_partition_joins_self.argtypes = [vp, u32, u32, u32, vp, vp, u64, vp, vp, vp, vp, vp, vp, vp]
     L.dj_set_hot_path.restype = i32
     L.dj_set_hot_path.argtypes = [vp, i32]
     if not os.environ.get("DJ_ENGINE_LIB") or hasattr(L, "dj_set_sweep_path"):     # an older build under A/B lacks it

@@ -1268,8 +1268,21 @@ extern "C" int dj_checkpoint_load(dj_engine* e, const char* path) {
 extern "C" int dj_partition_joins(dj_engine* e, uint32_t n, uint32_t n_ranks, const dj_join_rec* d_recs,
                                   const uint8_t* d_payloads, uint64_t pitch, dj_join_rec* d_recs_out,
                                   uint8_t* d_payloads_out, uint32_t* d_origin, uint32_t* d_counts, void* stream) {
+    return dj_partition_joins_self(e, n, n_ranks, 0xFFFFFFFFu, d_recs, d_payloads, pitch, d_recs_out, d_payloads_out, nullptr, nullptr,
+                                   d_origin, d_counts, stream);
+}
+
+extern "C" int dj_partition_joins_self(dj_engine* e, uint32_t n, uint32_t n_ranks, uint32_t self_rank, const dj_join_rec* d_recs,
+                                       const uint8_t* d_payloads, uint64_t pitch, dj_join_rec* d_recs_out,
+                                       uint8_t* d_payloads_out, dj_join_rec* d_recs_self, uint8_t* d_payloads_self,
+                                       uint32_t* d_origin, uint32_t* d_counts, void* stream) {
     if (!e) return DJ_E_INVALID;
     std::lock_guard<std::recursive_mutex> guard(e->mu);
+    if (self_rank != 0xFFFFFFFFu) {
+        if (self_rank >= n_ranks) return fail(e, DJ_E_INVALID, "partition: self_rank must be below n_ranks");
+        if (!d_recs_self || !aligned16(d_recs_self) || (d_payloads && (!d_payloads_self || !aligned16(d_payloads_self))))
+            return fail(e, DJ_E_INVALID, "partition: the buffers for this rank's own group are missing or misaligned");
+    }
     if (n_ranks < 1 || n_ranks > PART_MAX_RANKS) return fail(e, DJ_E_INVALID, "partition: n_ranks must be 1..%d", PART_MAX_RANKS);
     if (!d_recs || !d_recs_out || !d_origin || !d_counts) return fail(e, DJ_E_INVALID, "partition: null pointer");
     if (!aligned16(d_recs) || !aligned16(d_recs_out)) return fail(e, DJ_E_INVALID, "partition: records must be 16-byte aligned");
@@ -1291,7 +1304,7 @@ extern "C" int dj_partition_joins(dj_engine* e, uint32_t n, uint32_t n_ranks, co
     const uint32_t segs = (tiles + tiles_per_seg - 1) / tiles_per_seg;
     partition_count_kernel<<<segs, PART_BLOCK, 0, st>>>(d_recs, n, n_ranks, tiles_per_seg, scratch);
     const uint64_t lanes = d_payloads ? pitch / 16 : 1;
-#define DJ_SCATTER(G) partition_scatter_kernel<G><<<segs, PART_BLOCK, 0, st>>>(d_recs, n, n_ranks, tiles_per_seg, scratch, d_counts, d_recs_out, d_origin, d_payloads, d_payloads_out, pitch)
+#define DJ_SCATTER(G) partition_scatter_kernel<G><<<segs, PART_BLOCK, 0, st>>>(d_recs, n, n_ranks, tiles_per_seg, scratch, d_counts, d_recs_out, d_origin, d_payloads, d_payloads_out, pitch, self_rank, d_recs_self, d_payloads_self)
     if (lanes <= 4) DJ_SCATTER(4);
     else if (lanes <= 8) DJ_SCATTER(8);
     else if (lanes <= 16) DJ_SCATTER(16);

@@ -2289,9 +2289,14 @@ __global__ void __launch_bounds__(PART_BLOCK) partition_scatter_kernel(const dj_
                                                                        uint32_t tiles_per_seg, const uint32_t* seg_counts,
                                                                        uint32_t* counts_out, dj_join_rec* recs_out,
                                                                        uint32_t* origin, const uint8_t* pay_in,
-                                                                       uint8_t* pay_out, uint64_t pitch) {
+                                                                       uint8_t* pay_out, uint64_t pitch, uint32_t self_rank,
+                                                                       dj_join_rec* recs_self, uint8_t* pay_self) {
+    // self_rank < n_ranks: the rows of that rank's group go to recs_self / pay_self instead (row j of the group to row j
+    // there: the router lets this rank's own bucket land where its engine reads it); origin[] is indexed as if they
+    // had gone to their place in recs_out like everybody else's
     __shared__ uint32_t cnt[PART_GROUPS][PART_MAX_RANKS];
     __shared__ uint32_t tot[PART_MAX_RANKS], base[PART_MAX_RANKS];
+    __shared__ uint32_t self_base;
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t n_seg = gridDim.x;
     // where this segment's events start in each rank's group: the rank's events in earlier segments, behind
@@ -2310,7 +2315,10 @@ __global__ void __launch_bounds__(PART_BLOCK) partition_scatter_kernel(const dj_
     uint32_t mine = 0;
     if (threadIdx.x < n_ranks) {
         mine = base[threadIdx.x];
-        for (uint32_t r = 0; r < threadIdx.x; ++r) mine += tot[r];
+        uint32_t before = 0;
+        for (uint32_t r = 0; r < threadIdx.x; ++r) before += tot[r];
+        mine += before;
+        if (threadIdx.x == self_rank) self_base = before;
         if (blockIdx.x == 0) counts_out[threadIdx.x] = tot[threadIdx.x];
     }
     __syncthreads();
@@ -2355,9 +2363,15 @@ __global__ void __launch_bounds__(PART_BLOCK) partition_scatter_kernel(const dj_
         for (int k = 0; k < PART_EPT; ++k) {
             if (owner[k] == PART_NONE) { o[k] = PART_NONE; continue; }
             o[k] += cnt[k * (PART_BLOCK / 64) + wv][owner[k]];
-            reinterpret_cast<ulonglong2*>(recs_out)[2 * (size_t)o[k]] = a[k];
-            reinterpret_cast<ulonglong2*>(recs_out)[2 * (size_t)o[k] + 1] = b[k];
             origin[o[k]] = (uint32_t)(tile0 + k * PART_BLOCK + threadIdx.x);
+            dj_join_rec* to = recs_out;
+            if (owner[k] == self_rank) {             // from here on o[k] is the row in the self buffers, flagged
+                to = recs_self;
+                o[k] -= self_base;
+            }
+            reinterpret_cast<ulonglong2*>(to)[2 * (size_t)o[k]] = a[k];
+            reinterpret_cast<ulonglong2*>(to)[2 * (size_t)o[k] + 1] = b[k];
+            if (owner[k] == self_rank) o[k] |= 0x80000000u;
         }
         if (pay_in == nullptr) continue;
 #pragma unroll 1
@@ -2381,7 +2395,8 @@ __global__ void __launch_bounds__(PART_BLOCK) partition_scatter_kernel(const dj_
                     }
 #pragma unroll
                     for (int f = 0; f < FLIGHT; ++f)
-                        if (oo[f] != PART_NONE) nt_store(&reinterpret_cast<uint4*>(pay_out + (uint64_t)oo[f] * pitch)[c], v[f]);
+                        if (oo[f] != PART_NONE)
+                            nt_store(&reinterpret_cast<uint4*>(((oo[f] & 0x80000000u) ? pay_self : pay_out) + (uint64_t)(oo[f] & 0x7FFFFFFFu) * pitch)[c], v[f]);
                 }
             }
         }

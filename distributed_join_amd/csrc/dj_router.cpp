@@ -5,6 +5,11 @@
 // -> all-gather of the bucket sizes -> grouped send/recv of the buckets over RCCL (xGMI).  The
 // reference has no counterpart: its replicas share one Redis (reference src/distributed_join/redis.clj:13-15).
 //
+// A rank's OWN bucket never goes through the exchange: the partition writes it straight into the receive buffers
+// (dj_partition_joins_self), at the front, and every receiver's stream is "its own rows first, then the other sources in
+// rank order"; what arrives from the peers is placed right behind the own rows, so a piece is one contiguous run of
+// rows for one engine call.  With one rank nothing is copied at all.
+//
 // Safety under skew: every rank sees the whole matrix of bucket sizes, so every rank computes the
 // same plan (dj_route_plan): a receiver's incoming rows, in source-rank order, are cut into pieces
 // of at most max_recv rows and exchanged piece by piece.  No rank ever decides alone.
@@ -37,9 +42,13 @@ extern "C" uint32_t dj_route_plan(uint32_t world, uint32_t rank, const uint32_t*
         if (k > rounds) rounds = (uint32_t)k;
     }
     const uint64_t lo = (uint64_t)round * max_recv, hi = lo + max_recv;      // this round's window of every receiver's stream
+    // A receiver's stream: its OWN rows first (they never cross the exchange: the partition puts them where the
+    // receiver's engine reads them), then the other sources in rank order.
     auto piece = [&](uint32_t s, uint32_t r, uint32_t* off, uint32_t* cnt) {
-        uint64_t before = 0;                                                 // rows of lower source ranks in r's stream
-        for (uint32_t q = 0; q < s; ++q) before += matrix[(size_t)q * world + r];
+        uint64_t before = s == r ? 0 : matrix[(size_t)r * world + r];       // rows ahead of s's in r's stream
+        if (s != r)
+            for (uint32_t q = 0; q < s; ++q)
+                if (q != r) before += matrix[(size_t)q * world + r];
         const uint64_t end = before + matrix[(size_t)s * world + r];
         const uint64_t a = before > lo ? before : lo, b = end < hi ? end : hi;
         *off = a < b ? (uint32_t)(a - before) : 0;
@@ -133,6 +142,7 @@ struct Set {
     uint32_t returned_rounds = 0;     // pieces whose statuses have been sent back
     uint32_t issued = 0;              // pieces whose exchange has been queued (round or round + 1)
     uint32_t n_in = 0;                // rows of the piece queued last
+    uint32_t piece_at = 0;            // where that piece starts in the receive buffers (rows)
     uint32_t bucket_off[MAX_RANKS];   // where each destination's bucket starts in recs_sorted
 };
 }  // namespace
@@ -248,8 +258,10 @@ extern "C" int dj_router_create(dj_engine* e, uint32_t n_ranks, uint32_t rank, c
             R_HIP(nullptr, hipMalloc((void**)&s.matrix_d, (size_t)MAX_RANKS * (MAX_RANKS + 1) * 4));
             R_HIP(nullptr, hipHostMalloc((void**)&s.gathered_h, (size_t)MAX_RANKS * (MAX_RANKS + 1) * 4, hipHostMallocDefault));
             R_HIP(nullptr, hipHostMalloc((void**)&s.matrix_h, (size_t)MAX_RANKS * MAX_RANKS * 4, hipHostMallocDefault));
-            R_HIP(nullptr, hipMalloc((void**)&s.recv_recs, (size_t)max_recv * 32));
-            R_HIP(nullptr, hipMalloc((void**)&s.recv_pay, (size_t)max_recv * pitch));
+            // receive buffers: this rank's own bucket (up to max_send rows, written by the partition) with a round's
+            // arrivals (up to max_recv rows) right behind it
+            R_HIP(nullptr, hipMalloc((void**)&s.recv_recs, ((size_t)max_send + max_recv) * 32));
+            R_HIP(nullptr, hipMalloc((void**)&s.recv_pay, ((size_t)max_send + max_recv) * pitch));
             R_HIP(nullptr, hipMalloc((void**)&s.status_piece, (size_t)max_recv * 4));
             R_HIP(nullptr, hipMalloc((void**)&s.ret_sorted, (size_t)max_send * 4));
             R_HIP(nullptr, hipEventCreateWithFlags(&s.applied, hipEventDisableTiming));
@@ -302,8 +314,9 @@ extern "C" int dj_route_start(dj_router* r, uint32_t n, const dj_join_rec* d_rec
     s.planned = false;
     s.return_pending = false;
     s.round = s.rounds = s.issued = s.n_in = s.returned_rounds = 0;
-    int rc = dj_partition_joins(r->e, n, (uint32_t)r->world, d_recs, d_payloads, r->pitch, s.recs_sorted,
-                                s.has_pay ? s.pay_sorted : nullptr, s.origin, s.counts, r->stream);
+    int rc = dj_partition_joins_self(r->e, n, (uint32_t)r->world, (uint32_t)r->rank, d_recs, d_payloads, r->pitch, s.recs_sorted,
+                                     s.has_pay ? s.pay_sorted : nullptr, s.recv_recs, s.has_pay ? s.recv_pay : nullptr,
+                                     s.origin, s.counts, r->stream);
     if (rc != DJ_OK) return rfail(r, rc, "route: partition failed: %s", dj_last_error(r->e));
     // one more word behind the bucket sizes: does this rank's batch come with messages?  Every rank must agree (the
     // exchange pairs a send with a receive), and with the word in the gathered matrix every rank can check that
@@ -346,8 +359,19 @@ static int issue_piece(dj_router* r, Set& s) {
     }
     uint32_t send_off[MAX_RANKS], send_cnt[MAX_RANKS], recv_cnt[MAX_RANKS];
     dj_route_plan(w, (uint32_t)r->rank, s.matrix_h, r->max_recv, s.issued, send_off, send_cnt, recv_cnt);
-    uint32_t n_in = 0, at[MAX_RANKS];
-    for (uint32_t p = 0; p < w; ++p) { at[p] = n_in; n_in += recv_cnt[p]; }
+    // The piece: this round's part of the own bucket, rows [own_off, own_off + own_cnt) of it, which lie at the same
+    // rows of the receive buffers (the partition put the bucket at their front), and what the peers send, which goes
+    // right behind the own bucket's end while own rows are part of the piece (the bucket ends inside this round's
+    // window then) and to the front of the buffers otherwise (the own rows have all been consumed by earlier pieces).
+    const uint32_t me = (uint32_t)r->rank, own = s.matrix_h[(size_t)me * w + me];
+    const uint32_t own_off = send_off[me], own_cnt = send_cnt[me];
+    const bool window_has_own = (uint64_t)s.issued * r->max_recv < own;
+    const uint32_t piece_at = window_has_own ? own_off : 0;
+    uint32_t n_in = own_cnt, at[MAX_RANKS];
+    for (uint32_t p = 0; p < w; ++p) {
+        at[p] = piece_at + n_in;
+        if (p != me) n_in += recv_cnt[p];
+    }
     // records and messages of all peers in ONE group: one RCCL launch per piece (both sides issue records first,
     // then messages, so the two transfers between a pair of ranks match up in that order)
     R_NCCL(r, g_rccl.GroupStart());
@@ -357,12 +381,9 @@ static int issue_piece(dj_router* r, Set& s) {
             const uint8_t* src = pass == 0 ? reinterpret_cast<const uint8_t*>(s.recs_sorted) : s.pay_sorted;
             uint8_t* dst = pass == 0 ? reinterpret_cast<uint8_t*>(s.recv_recs) : s.recv_pay;
             for (uint32_t p = 0; p < w; ++p) {
+                if (p == me) continue;                   // in place already
                 const uint8_t* from = src + (size_t)(s.bucket_off[p] + send_off[p]) * row;
                 uint8_t* to = dst + (size_t)at[p] * row;
-                if ((int)p == r->rank) {
-                    if (send_cnt[p]) R_HIP(r, hipMemcpyAsync(to, from, (size_t)send_cnt[p] * row, hipMemcpyDeviceToDevice, r->comm_stream));
-                    continue;
-                }
                 if (send_cnt[p]) R_NCCL(r, g_rccl.Send(from, (size_t)send_cnt[p] * row, ncclUint8, (int)p, r->comm, r->comm_stream));
                 if (recv_cnt[p]) R_NCCL(r, g_rccl.Recv(to, (size_t)recv_cnt[p] * row, ncclUint8, (int)p, r->comm, r->comm_stream));
             }
@@ -375,6 +396,7 @@ static int issue_piece(dj_router* r, Set& s) {
     R_NCCL(r, ended);
     R_HIP(r, hipEventRecord(s.ready, r->comm_stream));
     s.n_in = n_in;
+    s.piece_at = piece_at;
     ++s.issued;
     return DJ_OK;
 }
@@ -407,8 +429,8 @@ extern "C" int dj_route_next(dj_router* r, int handle, const dj_join_rec** d_rec
         s.return_pending = false;
     }
     ++s.round;
-    *d_recs_out = s.recv_recs;
-    if (d_payloads_out) *d_payloads_out = s.has_pay ? s.recv_pay : nullptr;
+    *d_recs_out = s.recv_recs + s.piece_at;
+    if (d_payloads_out) *d_payloads_out = s.has_pay ? s.recv_pay + (size_t)s.piece_at * r->pitch : nullptr;
     *n_out = s.n_in;
     *more = s.round < s.rounds ? 1 : 0;
     return DJ_OK;
@@ -451,20 +473,24 @@ extern "C" int dj_route_return(dj_router* r, int handle) {
     // gets answers for, at the same places
     uint32_t send_off[MAX_RANKS], send_cnt[MAX_RANKS], recv_cnt[MAX_RANKS], at[MAX_RANKS];
     dj_route_plan(w, (uint32_t)r->rank, s.matrix_h, r->max_recv, s.round - 1, send_off, send_cnt, recv_cnt);
-    uint32_t n_in = 0;
-    for (uint32_t p = 0; p < w; ++p) { at[p] = n_in; n_in += recv_cnt[p]; }
+    const uint32_t me = (uint32_t)r->rank;
+    uint32_t n_in = send_cnt[me];                  // the piece's rows in order: own rows, then the peers' in rank order
+    for (uint32_t p = 0; p < w; ++p) {
+        at[p] = p == me ? 0 : n_in;
+        if (p != me) n_in += recv_cnt[p];
+    }
     // behind the engine call that writes the statuses (the caller has queued it), on the communication stream
     R_HIP(r, hipEventRecord(s.applied, r->engine_stream));
     R_HIP(r, hipStreamWaitEvent(r->comm_stream, s.applied, 0));
+    if (send_cnt[me])      // the answers to this rank's own rows stay here
+        R_HIP(r, hipMemcpyAsync(s.ret_sorted + s.bucket_off[me] + send_off[me], s.status_piece, (size_t)send_cnt[me] * 4,
+                                hipMemcpyDeviceToDevice, r->comm_stream));
     R_NCCL(r, g_rccl.GroupStart());
     auto queue_transfers = [&]() -> int {
         for (uint32_t p = 0; p < w; ++p) {
+            if (p == me) continue;
             const int32_t* from = s.status_piece + at[p];
             int32_t* to = s.ret_sorted + s.bucket_off[p] + send_off[p];
-            if ((int)p == r->rank) {
-                if (send_cnt[p]) R_HIP(r, hipMemcpyAsync(to, from, (size_t)send_cnt[p] * 4, hipMemcpyDeviceToDevice, r->comm_stream));
-                continue;
-            }
             if (recv_cnt[p]) R_NCCL(r, g_rccl.Send(from, (size_t)recv_cnt[p], ncclInt32, (int)p, r->comm, r->comm_stream));
             if (send_cnt[p]) R_NCCL(r, g_rccl.Recv(to, (size_t)send_cnt[p], ncclInt32, (int)p, r->comm, r->comm_stream));
         }

@@ -136,12 +136,18 @@ class Engine:
                                       h_result.ctypes.data_as(ctypes.c_void_p) if h_result is not None else None))
 
     def partition_joins_dev(self, n, n_ranks, d_recs, d_payloads, pitch, d_recs_out, d_payloads_out, d_origin, d_counts,
-                            stream_ptr=None):
-        self._check(self.L.dj_partition_joins(self.h, int(n), int(n_ranks), d_recs.data_ptr(),
-                                              d_payloads.data_ptr() if d_payloads is not None else None, int(pitch),
-                                              d_recs_out.data_ptr(),
-                                              d_payloads_out.data_ptr() if d_payloads_out is not None else None,
-                                              d_origin.data_ptr(), d_counts.data_ptr(), stream_ptr))
+                            stream_ptr=None, self_rank=None, d_recs_self=None, d_payloads_self=None):
+        """dj_partition_joins; with self_rank, dj_partition_joins_self: that rank's group goes to d_recs_self / d_payloads_self."""
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        if self_rank is None:
+            self._check(self.L.dj_partition_joins(self.h, int(n), int(n_ranks), d_recs.data_ptr(), ptr(d_payloads), int(pitch),
+                                                  d_recs_out.data_ptr(), ptr(d_payloads_out), d_origin.data_ptr(),
+                                                  d_counts.data_ptr(), stream_ptr))
+        else:
+            self._check(self.L.dj_partition_joins_self(self.h, int(n), int(n_ranks), int(self_rank), d_recs.data_ptr(),
+                                                       ptr(d_payloads), int(pitch), d_recs_out.data_ptr(), ptr(d_payloads_out),
+                                                       d_recs_self.data_ptr(), ptr(d_payloads_self), d_origin.data_ptr(),
+                                                       d_counts.data_ptr(), stream_ptr))
 
     # ---- host layer (numpy in, numpy out, synchronous) -----------------------------------------
     def _bufs(self):

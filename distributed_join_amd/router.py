@@ -7,7 +7,8 @@ sweeps, gathers, acks and recovers are GPU-local.
 
 route = partition (HIP kernels, dj_partition_joins: stable, so every owner sees the events of
 one source in array order) + all-gather of the bucket sizes + all_to_all_single calls (records,
-messages).  The receiver's order is: source rank 0's events, then rank 1's, ...
+messages).  The receiver's order is: its OWN events first (they never cross the exchange: the partition writes the own
+bucket straight into the receive buffers, dj_partition_joins_self), then the other source ranks' in rank order.
 
 Skew: every rank holds the whole matrix of bucket sizes, so every rank computes the same plan
 (dj_route_plan, the function the C router of include/dj_engine.h uses too): a receiver whose incoming
@@ -64,60 +65,92 @@ def gather_matrix(dist, group, send_counts, device=None):
     return torch.stack(parts).cpu().numpy().astype(np.uint32)
 
 
-def exchange_round(dist, group, rank, matrix, max_recv, rnd, recs_sorted, pay_sorted, recv_recs, recv_pay):
-    """One round of the planned exchange on any torch.distributed backend (RCCL on GPUs, gloo on CPU
-    tensors).  -> (rows received, rounds in all)."""
-    import torch
+def piece_layout(matrix, rank, max_recv, rnd):
+    """Where round `rnd`'s piece of `rank` lies in its receive buffers (rows): -> (rounds, send_off, send_cnt, recv_cnt,
+    piece_at, own_off, own_cnt, remote_at).  A receiver's stream is its OWN rows first (they never cross the exchange:
+    the partition puts the own bucket at the front of the receive buffers), then the other sources in rank order; what the
+    peers send in a round goes right behind the own bucket's end while own rows are part of the piece, else to the front."""
     rounds, send_off, send_cnt, recv_cnt = capi.route_plan(matrix, rank, max_recv, rnd)
+    own = int(matrix[rank][rank])
+    own_off, own_cnt = send_off[rank], send_cnt[rank]
+    has_own = rnd * max_recv < own
+    piece_at = own_off if has_own else 0
+    return rounds, send_off, send_cnt, recv_cnt, piece_at, own_off, own_cnt, piece_at + own_cnt
+
+
+def exchange_round(dist, group, rank, matrix, max_recv, rnd, recs_sorted, pay_sorted, recv_recs, recv_pay, own_in_place=False,
+                   layout=None):
+    """One round of the planned exchange on any torch.distributed backend (RCCL on GPUs, gloo on CPU
+    tensors).  recv_recs / recv_pay hold max_send + max_recv rows.  own_in_place: the partition has already put this
+    rank's own bucket at the front of the receive buffers (dj_partition_joins_self); otherwise it is copied there from
+    recs_sorted / pay_sorted here.  -> (rows of the piece, rounds in all, row of the receive buffers where the piece starts)."""
+    import torch
+    rounds, send_off, send_cnt, recv_cnt, piece_at, own_off, own_cnt, remote_at = layout or piece_layout(matrix, rank, max_recv, rnd)
+    if own_in_place and len(send_cnt) == 1:           # one rank: the partition's output is the piece
+        return own_cnt, rounds, piece_at
     bucket = [int(x) for x in matrix[rank]]
     starts = np.concatenate([[0], np.cumsum(bucket)[:-1]]).tolist()
-    n_in, n_out = sum(recv_cnt), sum(send_cnt)
-    whole = all(o == 0 and c == b for o, c, b in zip(send_off, send_cnt, bucket))
+    if not own_in_place and own_cnt:
+        a = starts[rank] + own_off
+        recv_recs[own_off:own_off + own_cnt] = recs_sorted[a:a + own_cnt]
+        if pay_sorted is not None:
+            recv_pay[own_off:own_off + own_cnt] = pay_sorted[a:a + own_cnt]
+    out_cnt = [0 if p == rank else c for p, c in enumerate(send_cnt)]
+    in_cnt = [0 if p == rank else c for p, c in enumerate(recv_cnt)]
+    n_remote, n_out = sum(in_cnt), sum(out_cnt)
 
     def rows(t):
-        if whole:
-            return t[:n_out]
-        return torch.cat([t[st + o:st + o + c] for st, o, c in zip(starts, send_off, send_cnt)])
+        parts = [t[st + o:st + o + c] for st, o, c in zip(starts, send_off, out_cnt) if c]
+        return torch.cat(parts) if parts else t[:0]
 
-    _dbg("round", rnd, "of", rounds, ":", n_out, "->", n_in)
-    dist.all_to_all_single(recv_recs[:n_in], rows(recs_sorted), output_split_sizes=recv_cnt, input_split_sizes=send_cnt,
-                           group=group)
-    if pay_sorted is not None:
-        dist.all_to_all_single(recv_pay[:n_in], rows(pay_sorted), output_split_sizes=recv_cnt, input_split_sizes=send_cnt,
-                               group=group)
-    return n_in, rounds
+    _dbg("round", rnd, "of", rounds, ":", n_out, "->", n_remote, "+ own", own_cnt)
+    if dist.get_world_size(group) > 1:
+        dist.all_to_all_single(recv_recs[remote_at:remote_at + n_remote], rows(recs_sorted), output_split_sizes=in_cnt,
+                               input_split_sizes=out_cnt, group=group)
+        if pay_sorted is not None:
+            dist.all_to_all_single(recv_pay[remote_at:remote_at + n_remote], rows(pay_sorted), output_split_sizes=in_cnt,
+                                   input_split_sizes=out_cnt, group=group)
+    return own_cnt + n_remote, rounds, piece_at
 
 
-def return_round(dist, group, rank, matrix, max_recv, rnd, status_piece, ret_sorted):
-    """The way back of round `rnd`: status_piece[:n_in] holds one answer per row this rank received in that round
-    (piece order); every answer goes to the rank its row came from and lands in ret_sorted at the place the row has
-    in that rank's recs_sorted.  The same plan as exchange_round, read backwards: one all_to_all_single."""
+def return_round(dist, group, rank, matrix, max_recv, rnd, status_piece, ret_sorted, layout=None):
+    """The way back of round `rnd`: status_piece[:n_in] holds one answer per row of that round's piece (own rows first,
+    then the peers' in rank order); every answer goes to the rank its row came from and lands in ret_sorted at the place
+    the row has in that rank's recs_sorted.  The same plan as exchange_round, read backwards: one all_to_all_single."""
     import torch
-    _, send_off, send_cnt, recv_cnt = capi.route_plan(matrix, rank, max_recv, rnd)
+    _, send_off, send_cnt, recv_cnt, _, own_off, own_cnt, _ = layout or piece_layout(matrix, rank, max_recv, rnd)
     bucket = [int(x) for x in matrix[rank]]
-    starts = np.concatenate([[0], np.cumsum(bucket)[:-1]]).tolist()
-    n_in, n_out = sum(recv_cnt), sum(send_cnt)
-    whole = all(o == 0 and c == b for o, c, b in zip(send_off, send_cnt, bucket))
-    back = ret_sorted[:n_out] if whole else torch.empty(n_out, dtype=ret_sorted.dtype, device=ret_sorted.device)
-    dist.all_to_all_single(back, status_piece[:n_in], output_split_sizes=send_cnt, input_split_sizes=recv_cnt, group=group)
-    if not whole:
-        at = 0
-        for st, o, c in zip(starts, send_off, send_cnt):
+    starts = [0]
+    for c in bucket[:-1]:
+        starts.append(starts[-1] + c)
+    if own_cnt:                                       # the answers to this rank's own rows stay here
+        a = starts[rank] + own_off
+        ret_sorted.narrow(0, a, own_cnt).copy_(status_piece.narrow(0, 0, own_cnt), non_blocking=True)
+    out_cnt = [0 if p == rank else c for p, c in enumerate(recv_cnt)]     # answers out = rows that came in
+    in_cnt = [0 if p == rank else c for p, c in enumerate(send_cnt)]
+    n_out, n_in = sum(out_cnt), sum(in_cnt)
+    if dist.get_world_size(group) == 1:
+        return
+    back = torch.empty(n_in, dtype=ret_sorted.dtype, device=ret_sorted.device)
+    dist.all_to_all_single(back, status_piece[own_cnt:own_cnt + n_out], output_split_sizes=in_cnt, input_split_sizes=out_cnt, group=group)
+    at = 0
+    for st, o, c in zip(starts, send_off, in_cnt):
+        if c:
             ret_sorted[st + o:st + o + c] = back[at:at + c]
             at += c
 
 
-def exchange(dist, group, recs_sorted, pay_sorted, send_counts, recv_recs, recv_pay):
+def exchange(dist, group, recs_sorted, pay_sorted, send_counts, recv_recs, recv_pay, max_recv):
     """all-to-all-v of records (rows of recs_sorted, grouped by destination rank) and messages (rows of
-    pay_sorted, optional) in as many rounds as the receive buffers need; the pieces are handed to `yield`-free
-    callers as a list: -> [(n_received, recv_recs copy, recv_pay copy or None), ...] in application order."""
+    pay_sorted, optional) in as many rounds as receivers with max_recv rows per round need; recv_recs / recv_pay are
+    scratch of at least len(recs_sorted) + max_recv rows.  -> [(n_received, records copy, messages copy or None), ...]
+    in application order."""
     rank = dist.get_rank(group)
     matrix = gather_matrix(dist, group, send_counts, device=recs_sorted.device)
     out, rnd, rounds = [], 0, 1
     while rnd < rounds:
-        n_in, rounds = exchange_round(dist, group, rank, matrix, recv_recs.shape[0], rnd, recs_sorted, pay_sorted,
-                                      recv_recs, recv_pay)
-        out.append((n_in, recv_recs[:n_in].clone(), recv_pay[:n_in].clone() if pay_sorted is not None else None))
+        n_in, rounds, at = exchange_round(dist, group, rank, matrix, max_recv, rnd, recs_sorted, pay_sorted, recv_recs, recv_pay)
+        out.append((n_in, recv_recs[at:at + n_in].clone(), recv_pay[at:at + n_in].clone() if pay_sorted is not None else None))
         rnd += 1
     return out
 
@@ -132,8 +165,10 @@ class _Slot:
         self.counts = torch.empty(64, dtype=torch.int32, device=dev)
         self.matrix_d = torch.empty(world * world, dtype=torch.int32, device=dev)
         self.matrix_h = torch.empty(world * world, dtype=torch.int32).pin_memory()
-        self.recv_recs = torch.empty((max_recv, 4), dtype=torch.int64, device=dev)
-        self.recv_pay = torch.empty((max_recv, pitch), dtype=torch.uint8, device=dev)
+        # this rank's own bucket (written here by the partition) with a round's arrivals right behind it
+        self.recv_recs = torch.empty((max_send + max_recv, 4), dtype=torch.int64, device=dev)
+        self.recv_pay = torch.empty((max_send + max_recv, pitch), dtype=torch.uint8, device=dev)
+        self.piece_at = 0                    # row of the receive buffers where the current piece starts
         self.status_piece = torch.empty(max_recv, dtype=torch.int32, device=dev)    # the engine's answers to the current piece
         self.ret_sorted = torch.empty(max_send, dtype=torch.int32, device=dev)      # answers to this rank's own records, bucket order
         self.returned = torch.cuda.Event()   # the latest piece's answers have left status_piece (router's stream)
@@ -152,6 +187,7 @@ class _Slot:
         self.matrix = None                   # numpy (world, world) once the sizes were read
         self.round = self.rounds = 0
         self.host = None                     # host-staged form: (records, messages) as CPU tensors
+        self.layout = None                   # piece_layout of the round exchanged last
 
 
 class Router:
@@ -183,28 +219,31 @@ class Router:
         torch = self.torch
         s = self.slots[self.turn]
         self.turn = (self.turn + 1) % len(self.slots)
-        with torch.cuda.stream(self.stream):
-            if s.free_pending:                    # the engine may still be reading this buffer set
-                self.stream.wait_event(s.free)
-                s.free_pending = False
-            if s.home_pending:                    # the scatter of this set's previous batch reads origin[]
-                self.stream.wait_event(s.home)
-                s.home_pending = False
-            s.has_pay = d_payloads is not None
-            s.matrix, s.round, s.rounds, s.host = None, 0, 0, None
-            s.n, s.returned_rounds, s.return_pending = int(n), 0, False
-            self.e.partition_joins_dev(n, self.world, d_recs, d_payloads, self.pitch, s.recs_sorted,
-                                       s.pay_sorted if s.has_pay else None, s.origin, s.counts,
-                                       stream_ptr=self.stream.cuda_stream)
-            if self.host_staged:
-                return s
-            s.parted.record(self.stream)
+        if s.free_pending:                    # the engine may still be reading this buffer set
+            self.stream.wait_event(s.free)
+            s.free_pending = False
+        if s.home_pending:                    # the scatter of this set's previous batch reads origin[]
+            self.stream.wait_event(s.home)
+            s.home_pending = False
+        s.has_pay = d_payloads is not None
+        s.matrix, s.round, s.rounds, s.host, s.layout = None, 0, 0, None, None
+        s.n, s.returned_rounds, s.return_pending = int(n), 0, False
+        self.e.partition_joins_dev(n, self.world, d_recs, d_payloads, self.pitch, s.recs_sorted,
+                                   s.pay_sorted if s.has_pay else None, s.origin, s.counts,
+                                   stream_ptr=self.stream.cuda_stream, self_rank=self.rank,
+                                   d_recs_self=s.recv_recs, d_payloads_self=s.recv_pay if s.has_pay else None)
+        if self.host_staged:
+            return s
+        s.parted.record(self.stream)
+        self.comm_stream.wait_event(s.parted)
+        w = self.world
         with torch.cuda.stream(self.comm_stream):
-            self.comm_stream.wait_event(s.parted)
-            w = self.world
-            self.dist.all_gather_into_tensor(s.matrix_d, s.counts[:w], group=self.group)
-            s.matrix_h.copy_(s.matrix_d, non_blocking=True)
-            s.sizes_in.record(self.comm_stream)
+            if w == 1:                        # nobody to ask: this rank's sizes are the matrix
+                s.matrix_h.copy_(s.counts[:1], non_blocking=True)
+            else:
+                self.dist.all_gather_into_tensor(s.matrix_d, s.counts[:w], group=self.group)
+                s.matrix_h.copy_(s.matrix_d, non_blocking=True)
+        s.sizes_in.record(self.comm_stream)
         return s
 
     def _plan(self, s):
@@ -216,34 +255,42 @@ class Router:
             counts = [int(x) for x in s.counts[:w].cpu().tolist()]
             s.matrix = gather_matrix(self.dist, self.group, counts)
             n_out = sum(counts)
-            s.host = (s.recs_sorted[:n_out].cpu(), s.pay_sorted[:n_out].cpu() if s.has_pay else None)
+            s.host = (s.recs_sorted[:n_out].cpu(), s.pay_sorted[:n_out].cpu() if s.has_pay else None)    # (the own bucket's rows in it are stale: never read)
         else:
             s.sizes_in.synchronize()                  # in long ago when the start was issued a batch ahead
-            s.matrix = s.matrix_h.numpy().astype(np.uint32).reshape(w, w).copy()
+            s.matrix = s.matrix_h.numpy().view(np.uint32).reshape(w, w)      # (pinned memory of this set: stays until the set's next start)
         _dbg("bucket sizes", s.matrix.tolist())
 
     def _exchange(self, s):
         torch = self.torch
         self._plan(s)
         lane = self.stream if self.host_staged else self.comm_stream
-        with torch.cuda.stream(lane):
-            if s.round > 0:
-                # the receive buffers are reused: the engine's kernels that read the previous piece are queued
-                s.free.record(self.engine_stream)
-                lane.wait_event(s.free)
-            if self.host_staged:
-                rr = torch.empty((self.max_recv, 4), dtype=torch.int64)
-                rp = torch.empty((self.max_recv, self.pitch), dtype=torch.uint8) if s.has_pay else None
+        if s.round > 0:
+            # the receive buffers are reused: the engine's kernels that read the previous piece are queued
+            s.free.record(self.engine_stream)
+            lane.wait_event(s.free)
+        s.layout = piece_layout(s.matrix, self.rank, self.max_recv, s.round)
+        if self.host_staged:
+            with torch.cuda.stream(lane):
+                rows = s.recv_recs.shape[0]
+                rr = torch.empty((rows, 4), dtype=torch.int64)
+                rp = torch.empty((rows, self.pitch), dtype=torch.uint8) if s.has_pay else None
                 self.stream.synchronize()
-                s.n_in, s.rounds = exchange_round(self.dist, self.group, self.rank, s.matrix, self.max_recv, s.round,
-                                                  s.host[0], s.host[1], rr, rp)
-                s.recv_recs[:s.n_in].copy_(rr[:s.n_in], non_blocking=False)
+                s.n_in, s.rounds, s.piece_at = exchange_round(self.dist, self.group, self.rank, s.matrix, self.max_recv, s.round,
+                                                              s.host[0], s.host[1], rr, rp, own_in_place=True, layout=s.layout)
+                # what came from the peers lies behind this round's own rows (which the partition put on the device)
+                a, b = s.piece_at + s.layout[6], s.piece_at + s.n_in
+                s.recv_recs[a:b].copy_(rr[a:b], non_blocking=False)
                 if s.has_pay:
-                    s.recv_pay[:s.n_in].copy_(rp[:s.n_in], non_blocking=False)
-            else:
-                s.n_in, s.rounds = exchange_round(self.dist, self.group, self.rank, s.matrix, self.max_recv, s.round,
-                                                  s.recs_sorted, s.pay_sorted if s.has_pay else None, s.recv_recs, s.recv_pay)
-            s.ready.record(lane)
+                    s.recv_pay[a:b].copy_(rp[a:b], non_blocking=False)
+        elif self.world == 1:
+            s.n_in, s.rounds, s.piece_at = s.layout[6], s.layout[0], s.layout[4]     # nothing to exchange
+        else:
+            with torch.cuda.stream(lane):
+                s.n_in, s.rounds, s.piece_at = exchange_round(self.dist, self.group, self.rank, s.matrix, self.max_recv, s.round,
+                                                              s.recs_sorted, s.pay_sorted if s.has_pay else None, s.recv_recs,
+                                                              s.recv_pay, own_in_place=True, layout=s.layout)
+        s.ready.record(lane)
         s.round += 1
 
     def _take(self, s):
@@ -266,21 +313,17 @@ class Router:
         torch = self.torch
         assert s.returned_rounds + 1 == s.round, "one return per piece, in order"
         lane = self.stream if self.host_staged else self.comm_stream
+        s.free.record(self.engine_stream)                 # behind the engine call that writes the statuses
+        lane.wait_event(s.free)
         with torch.cuda.stream(lane):
-            s.free.record(self.engine_stream)             # behind the engine call that writes the statuses
-            lane.wait_event(s.free)
             if self.host_staged:
                 lane.synchronize()
-                back = torch.empty(s.ret_sorted.shape[0], dtype=torch.int32)
-                return_round(self.dist, self.group, self.rank, s.matrix, self.max_recv, s.round - 1, s.status_piece.cpu(), back)
-                _, send_off, send_cnt, _ = capi.route_plan(s.matrix, self.rank, self.max_recv, s.round - 1)
-                starts = np.concatenate([[0], np.cumsum(s.matrix[self.rank].astype(np.int64))[:-1]]).tolist()
-                for st, o, c in zip(starts, send_off, send_cnt):
-                    if c:
-                        s.ret_sorted[st + o:st + o + c].copy_(back[st + o:st + o + c])
+                back = s.ret_sorted.cpu()
+                return_round(self.dist, self.group, self.rank, s.matrix, self.max_recv, s.round - 1, s.status_piece.cpu(), back, layout=s.layout)
+                s.ret_sorted.copy_(back)
             else:
-                return_round(self.dist, self.group, self.rank, s.matrix, self.max_recv, s.round - 1, s.status_piece, s.ret_sorted)
-            s.returned.record(lane)
+                return_round(self.dist, self.group, self.rank, s.matrix, self.max_recv, s.round - 1, s.status_piece, s.ret_sorted, layout=s.layout)
+        s.returned.record(lane)
         s.return_pending = True
         s.returned_rounds += 1
 
@@ -291,10 +334,9 @@ class Router:
         torch = self.torch
         assert s.returned_rounds == s.rounds and s.rounds > 0, "every piece's statuses must have returned"
         lane = self.stream if self.host_staged else self.comm_stream
-        with torch.cuda.stream(lane):
-            self.e._check(self.e.L.dj_scatter_statuses(self.e.h, s.n, s.origin.data_ptr(), s.ret_sorted.data_ptr(),
-                                                       d_status_out.data_ptr(), lane.cuda_stream))
-            s.home.record(lane)
+        self.e._check(self.e.L.dj_scatter_statuses(self.e.h, s.n, s.origin.data_ptr(), s.ret_sorted.data_ptr(),
+                                                   d_status_out.data_ptr(), lane.cuda_stream))
+        s.home.record(lane)
         s.home_pending = True
         if wait_stream is not None:
             wait_stream.wait_event(s.home)
@@ -312,7 +354,7 @@ class Router:
         engine's stream waits for the exchange; the host does not (beyond the bucket sizes)."""
         self.advance(s)
         self._take(s)
-        return s.recv_recs, (s.recv_pay if s.has_pay else None), s.n_in
+        return s.recv_recs[s.piece_at:], (s.recv_pay[s.piece_at:] if s.has_pay else None), s.n_in
 
     def more(self, s):
         """True while pieces are left (the same answer on every rank)."""
@@ -323,7 +365,7 @@ class Router:
         piece has been queued.  A collective."""
         self._exchange(s)
         self._take(s)
-        return s.recv_recs, (s.recv_pay if s.has_pay else None), s.n_in
+        return s.recv_recs[s.piece_at:], (s.recv_pay[s.piece_at:] if s.has_pay else None), s.n_in
 
     def release(self, s):
         """Call after the kernels that read the routed batch have been queued on the engine's stream."""

@@ -402,6 +402,16 @@ int dj_partition_joins(dj_engine* e, uint32_t n, uint32_t n_ranks,
                        dj_join_rec* d_recs_out, uint8_t* d_payloads_out,
                        uint32_t* d_origin, uint32_t* d_counts, void* stream);
 
+/* The same partition with ONE rank's group written elsewhere: row j of self_rank's group goes to d_recs_self[j] (and
+ * d_payloads_self + j * pitch) instead of its place in d_recs_out; all other groups, d_counts and d_origin are as above
+ * (d_origin is indexed as if the group had stayed in d_recs_out, whose rows for it are left untouched).  The router
+ * uses it to let a rank's own bucket land directly where its engine reads it: no copy through the exchange. */
+int dj_partition_joins_self(dj_engine* e, uint32_t n, uint32_t n_ranks, uint32_t self_rank,
+                            const dj_join_rec* d_recs, const uint8_t* d_payloads, uint64_t pitch,
+                            dj_join_rec* d_recs_out, uint8_t* d_payloads_out,
+                            dj_join_rec* d_recs_self, uint8_t* d_payloads_self,
+                            uint32_t* d_origin, uint32_t* d_counts, void* stream);
+
 /* The inverse of the partition's move, for per-record answers: d_out[d_origin[j]] = d_sorted[j] for j < n, where
  * d_sorted[j] answers the record that dj_partition_joins put at place j.  Every origin index must be below the n of
  * that partition call (they are, when d_origin is what it wrote).  stream as in dj_partition_joins. */

@@ -186,3 +186,19 @@ class ParityDriver:
             w = self._canon(om, k, ol, omw, op_)
             assert g == w, f"snapshot of {self.ids[k]} differs:\n engine {g}\n oracle {w}"
             assert self.e.queue_scores(self.fps[k, 0], self.fps[k, 1]) == self.o.queue_scores(k), f"queue scores of {self.ids[k]}"
+
+
+def routed_order(owners_by_rank):
+    """The order in which ONE store must apply the streams of several ranks so that every barrier sees its events as the
+    router delivers them: barriers of owner r get r's own events first (they never cross the exchange), then the other
+    ranks' in rank order, each rank's in its submission order.  owners_by_rank[s] = owner rank of every event of rank s.
+    -> [(source rank, indices into that rank's stream), ...]; barriers of different owners do not interact, so the
+    segments of one owner may follow those of another."""
+    world = len(owners_by_rank)
+    out = []
+    for r in range(world):
+        for s in [r] + [q for q in range(world) if q != r]:
+            idx = np.nonzero(np.asarray(owners_by_rank[s]) == r)[0]
+            if len(idx):
+                out.append((s, idx))
+    return out

@@ -4,7 +4,7 @@
 // return to the rank that submitted the record (dj_route_status_buffer / dj_route_return / dj_route_statuses).
 //
 // Checked against the CPU oracle (oracle/dj_oracle.h, the checker) on ONE store: the concatenated stream — batch by
-// batch, rank 0's records first, then rank 1's, ... (the router's global order) — must give, for every rank, exactly
+// batch, and for every owner its own rank's records first, then the other ranks' (the router's order) — must give, for every rank, exactly
 // the per-record statuses that came home to it, in its own submission order: WAITING / COMPLETE (core.clj:55,58),
 // 404 for ids nobody forked and 400 for positions beyond the count (redis.clj:152-153).  A hot barrier makes its
 // owner take every batch in several rounds.  At the end every engine pops what is due; together they must pop as many
@@ -228,28 +228,38 @@ int main(int argc, char** argv) {
         for (uint32_t k = 0; k <= total; ++k) idx[k] = k;
         djo_fork_batch(o, total + 1, idx.data(), cnt.data(), dl.data(), st.data());
     }
+    // batch by batch; inside a batch owner by owner (barriers of different owners do not interact), and for an owner its
+    // own rank's records first, then the other ranks' in rank order: the order in which the router delivers them
     long seen[8] = {0};
-    for (int b = 0; b < B; ++b)
-        for (int r = 0; r < N; ++r) {
-            std::vector<uint32_t> idx(n), pos(n), len(n, PITCH), mw(n, 0);
-            std::vector<uint8_t> pay((size_t)n * PITCH);
-            std::vector<int32_t> st(n);
-            for (uint32_t i = 0; i < n; ++i) {
-                const Event ev = make_event(r, b, i, total, hot);
-                idx[i] = ev.id; pos[i] = ev.position;
-                make_msg(&pay[(size_t)i * PITCH], r, b, i);
+    for (int b = 0; b < B; ++b) {
+        std::vector<std::vector<int32_t>> want(N, std::vector<int32_t>(n, 0));
+        for (int owner = 0; owner < N; ++owner)
+            for (int q = 0; q < N; ++q) {
+                const int r = q == 0 ? owner : (q <= owner ? q - 1 : q);
+                std::vector<uint32_t> idx, pos, len, mw, which;
+                std::vector<uint8_t> pay;
+                for (uint32_t i = 0; i < n; ++i) {
+                    const Event ev = make_event(r, b, i, total, hot);
+                    if ((int)dj_owner_of(fp[2 * ev.id], fp[2 * ev.id + 1], (uint32_t)N) != owner) continue;
+                    idx.push_back(ev.id); pos.push_back(ev.position); len.push_back(PITCH); mw.push_back(0); which.push_back(i);
+                    pay.resize(pay.size() + PITCH);
+                    make_msg(&pay[pay.size() - PITCH], r, b, i);
+                }
+                std::vector<int32_t> st(idx.size());
+                djo_join_batch(o, (uint32_t)idx.size(), idx.data(), pos.data(), len.data(), mw.data(), pay.data(), PITCH, T0 + 5 + (uint64_t)b, st.data());
+                for (size_t k = 0; k < st.size(); ++k) want[r][which[k]] = st[k];
             }
-            djo_join_batch(o, n, idx.data(), pos.data(), len.data(), mw.data(), pay.data(), PITCH, T0 + 5 + (uint64_t)b, st.data());
+        for (int r = 0; r < N; ++r)
             for (uint32_t i = 0; i < n; ++i) {
-                if (st[i] >= 0 && st[i] < 8) ++seen[st[i]];
-                if (answers[r][b].size() != n || answers[r][b][i] != st[i]) {
+                if (want[r][i] >= 0 && want[r][i] < 8) ++seen[want[r][i]];
+                if (answers[r][b].size() != n || answers[r][b][i] != want[r][i]) {
                     fprintf(stderr, "rank %d batch %d: record %u was answered %d, one store answers %d\n", r, b, i,
-                            answers[r][b].size() == n ? answers[r][b][i] : -999, st[i]);
+                            answers[r][b].size() == n ? answers[r][b][i] : -999, want[r][i]);
                     ++sh.failures;
                     break;
                 }
             }
-        }
+    }
     std::vector<djo_cont> oc(total + 64);
     const long want_popped = (long)djo_pop_due(o, T0 + 1000, total + 64, oc.data());
     if (want_popped != sh.popped.load()) { fprintf(stderr, "the engines popped %ld barriers, one store pops %ld\n", sh.popped.load(), want_popped); ++sh.failures; }

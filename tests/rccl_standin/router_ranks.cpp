@@ -4,8 +4,8 @@
 //
 // Every rank routes B batches of n records with their messages; a share of all records names one hot barrier, so its
 // owner's incoming rows exceed max_recv and every batch takes several rounds.  Checked per rank and batch: the pieces,
-// put one behind the other, are exactly the records this rank owns (dj_owner_of) from rank 0's batch in array order,
-// then from rank 1's, ..., each with its message; and the answers to them (one word per record, here a function of the
+// put one behind the other, are exactly the records this rank owns (dj_owner_of): from its own batch first (they never
+// cross the exchange), then from rank 0's batch in array order, rank 1's, ..., each with its message; and the answers to them (one word per record, here a function of the
 // record) come back to the rank that submitted the record, in its own submission order.  Batches are started ahead (two in flight) and every other batch's
 // first piece is sent ahead of its use (dj_route_advance), as a pipelined host would.
 //
@@ -181,7 +181,8 @@ int main(int argc, char** argv) {
                 size_t k = 0;
                 bool ok = true;
                 uint8_t row[PITCH];
-                for (int s = 0; s < N && ok; ++s)
+                for (int q = 0; q < N && ok; ++q) {
+                    const int s = q == 0 ? r : (q <= r ? q - 1 : q);       // this rank's own records first, then the others in rank order
                     for (uint32_t i = 0; i < n; ++i) {
                         const dj_join_rec want = make_rec(s, b, i, hot);
                         if ((int)dj_owner_of(want.fp_lo, want.fp_hi, (uint32_t)N) != r) continue;
@@ -193,6 +194,7 @@ int main(int argc, char** argv) {
                         }
                         ++k;
                     }
+                }
                 if (ok && k != got.size()) { fprintf(stderr, "rank %d batch %d: %zu rows too many\n", r, b, got.size() - k); ok = false; }
                 if (!ok) ++sh.failures;
             }

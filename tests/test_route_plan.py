@@ -1,7 +1,7 @@
 """dj_route_plan (the exchange plan both routers use): on every rank the same matrix of bucket sizes must give a
 consistent set of rounds - what s sends to r in a round is what r expects from s, no receiver takes more than
-its buffer holds in one round, and the rounds hand every receiver its incoming records exactly once, in
-source-rank order."""
+its buffer holds in one round, and the rounds hand every receiver its incoming records exactly once: its own
+rows first (they stay on the rank), then the other sources in rank order."""
 import numpy as np
 
 from distributed_join_amd import capi
@@ -25,13 +25,15 @@ def check(matrix, max_recv):
             recv = plans[r, rnd][2]
             assert sum(recv) <= max_recv
             started = False
-            for s in range(w):
+            for s in [r] + [q for q in range(w) if q != r]:      # the receiver's stream order
                 so, sc, _ = plans[s, rnd]
                 assert sc[r] == recv[s], "sender and receiver disagree"
                 if sc[r]:
                     assert so[r] == taken[s], "pieces of a bucket must follow each other"
-                    # source order inside the receiver's stream: lower sources are complete before a higher one starts
-                    assert all(taken[q] == matrix[q, r] for q in range(s))
+                    # source order inside the receiver's stream: its own rows first, then the other sources in rank order;
+                    # every source ahead of s is complete before s starts
+                    ahead = [] if s == r else [r] + [q for q in range(s) if q != r]
+                    assert all(taken[q] == matrix[q, r] for q in ahead)
                     started = True
                 taken[s] += sc[r]
             # a round is full unless it is the receiver's last

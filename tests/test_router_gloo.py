@@ -46,6 +46,11 @@ def gen_stream(rank):
     return b, pos, pay
 
 
+def capi_fps(ids):
+    from distributed_join_amd import capi
+    return capi.fingerprint_many(ids)
+
+
 def stable_partition(owners, world):
     order = np.argsort(owners, kind="stable")
     counts = np.bincount(owners, minlength=world)
@@ -77,16 +82,17 @@ def worker(rank, port, out_dir):
         order, counts = stable_partition(own, WORLD)
         rs = torch.from_numpy(recs[order].copy())
         ps = torch.from_numpy(pay[order].copy()) if pay is not None else None
-        rr = torch.zeros((RECV_CAP, recs.shape[1]), dtype=torch.int64)
-        rp = torch.zeros((RECV_CAP, P), dtype=torch.uint8) if pay is not None else None
+        rr = torch.zeros((len(recs) + RECV_CAP, recs.shape[1]), dtype=torch.int64)      # own bucket + a round's arrivals
+        rp = torch.zeros((len(recs) + RECV_CAP, P), dtype=torch.uint8) if pay is not None else None
         matrix = gather_matrix(dist, dist.group.WORLD, counts)
         ret_sorted = torch.full((len(recs),), -1, dtype=torch.int32)
         rnd, n_rounds = 0, 1
         while rnd < n_rounds:
-            n_in, n_rounds = exchange_round(dist, dist.group.WORLD, rank, matrix, RECV_CAP, rnd, rs, ps, rr, rp)
-            got = rr[:n_in].numpy()
+            n_in, n_rounds, at = exchange_round(dist, dist.group.WORLD, rank, matrix, RECV_CAP, rnd, rs, ps, rr, rp)
+            assert n_in <= RECV_CAP
+            got = rr[at:at + n_in].numpy()
             assert (owners_all[got[:, 0]] == rank).all()                # only my barriers arrive
-            st = apply(got, rp[:n_in].numpy() if pay is not None else None)
+            st = apply(got, rp[at:at + n_in].numpy() if pay is not None else None)
             return_round(dist, dist.group.WORLD, rank, matrix, RECV_CAP, rnd, torch.from_numpy(np.asarray(st, dtype=np.int32)), ret_sorted)
             rnd += 1
         rounds.append(n_rounds)
@@ -127,17 +133,23 @@ def test_two_ranks_fire_what_one_store_fires(tmp_path, oracle_lib):
         part = np.load(tmp_path / f"fired_{r}.npy", allow_pickle=True)[0]
         assert not (fired.keys() & part.keys()), "a barrier fired on two ranks"
         fired.update(part)
-    # the same global stream on one store: rank 0's events first, then rank 1's
     ids = [f"j{b:x}~t{b:x}" for b in range(WORLD * NB + 1 + GHOSTS)]
     o = oracle_lib.Oracle(ids, max_count=C, payload_stride=P)
     o.fork_batch(np.arange(WORLD * NB + 1), np.full(WORLD * NB + 1, C), np.full(WORLD * NB + 1, T0 + 3_600_000))
+    # the same requests on one store, in the router's order: an owner's own events first, then the other ranks'
+    from distributed_join_amd.router import owner_of_np
+    from tests.parity import routed_order
+    owners_all = owner_of_np(capi_fps(ids)[:, 1], WORLD)
+    streams = [gen_stream(r) for r in range(WORLD)]
+    want = [np.zeros(len(st[0]), dtype=np.int32) for st in streams]
+    for src, idx in routed_order([owners_all[st[0]] for st in streams]):
+        b, pos, pay = streams[src]
+        want[src][idx] = o.join_batch(b[idx], pos[idx], np.full(len(idx), P), np.zeros(len(idx)), pay[idx], T0 + 5)
     seen = set()
     for r in range(WORLD):
-        b, pos, pay = gen_stream(r)
-        st = o.join_batch(b, pos, np.full(len(b), P), np.zeros(len(b)), pay, T0 + 5)
         # every request's answer came home to the rank that sent it, in that rank's own order
         got = np.load(tmp_path / f"answers_{r}.npy")
-        assert got.tolist() == np.asarray(st, dtype=np.int32).tolist(), f"rank {r}: answers differ from one store's"
+        assert got.tolist() == want[r].tolist(), f"rank {r}: answers differ from one store's"
         seen |= set(got.tolist())
     assert seen == {1, 2, 3, 4}, "the streams hold WAITING, COMPLETE, 404 and 400 answers"
     hm, hl, _, hp = o.snapshot_one(HOT)

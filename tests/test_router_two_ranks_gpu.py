@@ -4,8 +4,8 @@ buckets cross ranks with the planned all-to-all-v over gloo, staged through host
 two ranks of one RCCL communicator cannot share a device), and each rank applies what it owns.  One
 barrier receives as many events again as all the others together, so its owner takes its rows in several
 rounds (the receive buffers hold MAX_RECV rows).  The union of what the two engines fire, and what the hot
-barrier holds, must be what the oracle has after the whole stream in the router's global order (rank 0's
-events, then rank 1's, ...).  Every request's answer (WAITING, COMPLETE, 404 for an id nobody forked, 400 for a
+barrier holds, must be what the oracle has after the whole stream in the router's order (for every owner: its
+own events first, then the other ranks' in rank order).  Every request's answer (WAITING, COMPLETE, 404 for an id nobody forked, 400 for a
 position beyond the count) is computed by the owner's engine and returns to the rank that submitted the request
 (Router.return_statuses / statuses): each rank's answers, in its own submission order, must be the oracle's for
 that rank's part of the stream (ring.clj:54-69, core.clj:52-58, redis.clj:152-159)."""
@@ -143,12 +143,19 @@ def test_engine_processes_fire_what_one_store_fires(tmp_path, oracle_lib, WORLD)
     ids = [f"j{b:x}~t{b:x}" for b in range(WORLD * NB + 1 + GHOSTS)]
     o = oracle_lib.Oracle(ids, max_count=C, payload_stride=P)
     o.fork_batch(np.arange(WORLD * NB + 1), np.full(WORLD * NB + 1, C), np.full(WORLD * NB + 1, T0 + 3_600_000))
+    # the same requests on one store, in the router's order: an owner's own events first, then the other ranks'
+    from distributed_join_amd.router import owner_of_np
+    from tests.parity import routed_order
+    owners_all = owner_of_np(capi.fingerprint_many(ids)[:, 1], WORLD)
+    streams = [gen_stream(r, WORLD) for r in range(WORLD)]
+    want_st = [np.zeros(len(st[0]), dtype=np.int32) for st in streams]
+    for src, idx in routed_order([owners_all[st[0]] for st in streams]):
+        b, pos, pay = streams[src]
+        want_st[src][idx] = o.join_batch(b[idx], pos[idx], np.full(len(idx), P), np.zeros(len(idx)), pay[idx], T0 + 5)
     seen = set()
     for r in range(WORLD):
-        b, pos, pay = gen_stream(r, WORLD)
-        st = o.join_batch(b, pos, np.full(len(b), P), np.zeros(len(b)), pay, T0 + 5)
         got = np.load(tmp_path / f"answers_{r}.npy")
-        assert got.tolist() == np.asarray(st, dtype=np.int32).tolist(), f"rank {r}: the answers that came home differ from one store's"
+        assert got.tolist() == want_st[r].tolist(), f"rank {r}: the answers that came home differ from one store's"
         seen |= set(got.tolist())
     assert seen == {capi.DJ_JOIN_WAITING, capi.DJ_JOIN_COMPLETE, capi.DJ_JOIN_NOT_FOUND, capi.DJ_JOIN_BAD_POSITION}
     _, hl, _, hp = o.snapshot_one(HOT)
