@@ -61,6 +61,7 @@ struct dj_engine {
     Slot* slots_alt;             // second table for dj_compact (always all-empty between calls)
     uint64_t* q_alt;
     uint32_t n_cus;              // compute units of the device
+    uint32_t bfat_max;           // largest number of sub-ranges per bucket the key buffer was sized for
     int bucket_mode;             // -1: the bucketed join passes where they pay; 0: never; 1: wherever they apply (tests)
     int fuse_off;                // 1: the link pass never copies messages itself (dj_set_hot_path mode + 4: tests of the separate copy pass)
     int hlen_mode;               // 1: join statuses carry HLEN above DJ_JOIN_HLEN_SHIFT (dj_set_join_hlen)
@@ -311,10 +312,15 @@ static int create_impl(dj_engine* e) {
     e->live_bank = 0;
     ALLOC(e, e->d_counters, 2 * C_COUNT * 4);
     HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, 2 * C_COUNT * 4, e->stream));
-    ALLOC(e, w.bkeys, (size_t)BK_MAX_BUCKETS * RB_CAP * 8);
+    // room for the keys of one batch of max_batch events: each of the 1024 buckets holds bfat_max x RB_CAP keys
+    e->bfat_max = 1;
+    while ((uint64_t)BK_MAX_BUCKETS * BK_MEAN_MAX * e->bfat_max < nb && e->bfat_max < 16) e->bfat_max <<= 1;
+    ALLOC(e, w.bkeys, (size_t)BK_MAX_BUCKETS * RB_CAP * e->bfat_max * 8);
     ALLOC(e, w.bcursor, BK_MAX_BUCKETS * 4);
     HIP_TRY(e, hipMemsetAsync(w.bcursor, 0, BK_MAX_BUCKETS * 4, e->stream));
-    w.bbuckets = w.bshift = 0;
+    w.bbuckets = w.bshift = w.bsubshift = 0;
+    w.bcap = RB_CAP;
+    w.bfat = 1;
     ALLOC(e, w.cx_keys, CX_HASH * 4);
     ALLOC(e, w.cx_val, CX_HASH * 4);
     ALLOC(e, w.cx_off, CX_CAP * 4);
@@ -632,7 +638,9 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
     // large launches; a batch that IS about 2^20 events gains on a table of any size — 2^25 slots, link + resolve: 132 us
     // chained, 121 us bucketed), and whose previous batch showed no long chains (a hot barrier overflows its bucket, and the batch then falls back to chains).
     const uint64_t slots = e->t.mask + 1;
-    bool bucket = !serial_only && w.fused && !wide && n <= BK_MAX_BUCKETS * BK_MEAN_MAX && e->bucket_mode != 0 &&
+    // Batches beyond 1024 buckets x 1280 events: the buckets get fat (bfat x 2048 keys) and the second pass works through
+    // a bucket's slot range in bfat sub-ranges; one launch pair whatever the batch size, up to what the key buffer holds.
+    bool bucket = !serial_only && w.fused && !wide && n <= (uint64_t)BK_MAX_BUCKETS * BK_MEAN_MAX * e->bfat_max && e->bucket_mode != 0 &&
                   (e->bucket_mode == 1 || (n >= 196608 && hint[0] < 2048 && hint[1] < 512));
     if (bucket) {
         uint32_t B = 16;
@@ -640,9 +648,16 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
         while (B > 1 && (uint64_t)B * 4 > slots) B >>= 1;
         uint32_t shift = 0;
         while ((slots >> shift) > B) ++shift;
+        uint32_t fat = 1;
+        while ((uint64_t)B * BK_MEAN_MAX * fat < n && fat < e->bfat_max && (shift >> 1) && (1u << shift) / (fat * 2) >= 4) fat <<= 1;
+        uint32_t fat_log = 0;
+        while ((1u << fat_log) < fat) ++fat_log;
         w.bbuckets = B;
         w.bshift = shift;
-        bucket = (uint64_t)B * BK_MEAN_MAX >= n;        // (a tiny table cannot spread a large batch)
+        w.bfat = fat;
+        w.bcap = fat * RB_CAP;
+        w.bsubshift = shift - fat_log;
+        bucket = (uint64_t)B * BK_MEAN_MAX * fat >= n;        // (a tiny table cannot spread a large batch)
     }
     // equal tiles of the first pass: one per compute unit (two above 4096 events per unit; a unit holds two blocks),
     // none below 1024 events; 2^20 events on 256 units: 256 tiles of 4096.  A batch of 257 tiles of 4096 took
@@ -652,6 +667,11 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
         const uint32_t most = e->n_cus * (n > (uint64_t)e->n_cus * BK_TILE ? 2u : 1u);
         tiles = grid_for(n, BK_BLOCK);
         if (tiles > most) tiles = most;
+        if ((uint64_t)tiles * BK_TILE < n) {
+            // more than two tiles of 4096 events per unit: whole rounds of (two tiles per unit), the tiles a little under 4096
+            const uint32_t round = 2 * e->n_cus;
+            tiles = (grid_for(n, BK_TILE) + round - 1) / round * round;
+        }
         tile_events = (uint32_t)(((n + tiles - 1) / tiles + 63) & ~63ull);
         tiles = grid_for(n, tile_events);
         ept = (tile_events + BK_BLOCK - 1) / BK_BLOCK;
@@ -667,7 +687,11 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
         else LAUNCH(e, DJ_PROF_JOIN_LINK, DJ_LINKB(64));
 #undef DJ_LINKB1
 #undef DJ_LINKB
-        LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_bucket_kernel<<<w.bbuckets, RB_T, 0, e->stream>>>(e->t, w, d_recs, n, now_ms, d_status)));
+        if (w.bfat > 1) {
+            LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_bucket_kernel<true><<<w.bbuckets * w.bfat, RB_T, 0, e->stream>>>(e->t, w, d_recs, n, now_ms, d_status)));
+            HIP_TRY(e, hipMemsetAsync(w.bcursor, 0, (size_t)w.bbuckets * 4, e->stream));
+        }
+        else LAUNCH(e, DJ_PROF_JOIN_RESOLVE, (join_resolve_bucket_kernel<false><<<w.bbuckets, RB_T, 0, e->stream>>>(e->t, w, d_recs, n, now_ms, d_status)));
     } else {
 #define DJ_LINK(HOT, G, BLOCK) join_link_kernel<HOT, G><<<grid_for(n, BLOCK), BLOCK, 0, e->stream>>>(e->t, w, d_recs, n, pitch, d_status, d_payloads)
     if (w.cx_on) LAUNCH(e, DJ_PROF_JOIN_LINK, (DJ_LINK(true, 0, LINK_BLOCK_HOT)));

@@ -610,7 +610,7 @@ join_link_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, ui
         if (tix < B) {
             off[tix] = bw + incl - c;
             base[tix] = c ? a_add(&w.bcursor[tix], c) : 0u;
-            if (c && base[tix] + c > (uint32_t)RB_CAP) a_store(&w.counters[C_BOVF], 1u);
+            if (c && base[tix] + c > w.bcap) a_store(&w.counters[C_BOVF], 1u);
         }
     }
     __syncthreads();
@@ -626,10 +626,17 @@ join_link_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, ui
     for (uint32_t e = tix; e < total; e += BK_BLOCK) {
         const uint32_t bq = stage_b[e];
         const uint32_t at = base[bq] + (e - off[bq]);
-        if (at < (uint32_t)RB_CAP) w.bkeys[(size_t)bq * RB_CAP + at] = stage[e];
+        if (at < w.bcap) w.bkeys[(size_t)bq * w.bcap + at] = stage[e];
     }
 }
 
+// FAT: a batch of millions of events files more keys per bucket than the LDS below holds (w.bfat times RB_CAP at most): the
+// bucket's slot range is then cut into w.bfat sub-ranges with a block each (block = sub-range x buckets + bucket: the
+// blocks of one bucket run on one XCD and find its keys in that L2 after the first has read them); a block reads all
+// keys of its bucket and keeps those of its sub-range.  A sub-range that still holds more than RB_CAP keys (a hot barrier
+// nobody has flagged) chains its events on their slots the way join_link_kernel does and hands its barriers to the
+// long-chain pass.  The host clears the cursors after a FAT launch (no block knows when its bucket's others have read theirs).
+template <bool FAT>
 __global__ void __launch_bounds__(RB_T) __attribute__((amdgpu_waves_per_eu(8)))
 join_resolve_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint64_t now, int32_t* status) {
     __shared__ uint32_t hkey[RB_H];        // slot inside the range + 1, 0 = free
@@ -637,14 +644,18 @@ join_resolve_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n,
     __shared__ uint16_t nxt[RB_CAP];       // the key filed before it on the same slot + 1, 0 = none: the slot's first key
     __shared__ uint16_t cellof[RB_CAP];
     __shared__ uint64_t kbuf[RB_CAP];
-    const uint32_t tix = threadIdx.x, b = blockIdx.x;
+    __shared__ uint32_t sub_n;
+    const uint32_t tix = threadIdx.x, blk = blockIdx.x;
+    const uint32_t b = FAT ? blk & (w.bbuckets - 1) : blk, sub = FAT ? blk / w.bbuckets : 0u;
     uint32_t nb = w.bcursor[b];
-    __syncthreads();
-    if (tix == 0) w.bcursor[b] = 0;        // for the next batch
+    if (!FAT) {
+        __syncthreads();
+        if (tix == 0) w.bcursor[b] = 0;    // for the next batch
+    }
     if (a_load(&w.counters[C_BOVF]) != 0) {
         // A bucket overflowed (the same answer in every thread of every block): every linked event enters its barrier's
         // chain the way join_link_kernel does it, and every touched barrier goes on the long-chain pass's list.
-        for (uint64_t i0 = (uint64_t)b * RB_T; i0 < n; i0 += (uint64_t)gridDim.x * RB_T) {
+        for (uint64_t i0 = (uint64_t)blk * RB_T; i0 < n; i0 += (uint64_t)gridDim.x * RB_T) {
             const uint64_t i = i0 + tix;
             const uint32_t s = i < n ? w.ev_slot[i] : 0xFFFFFFFFu;
             bool first = false;
@@ -660,9 +671,48 @@ join_resolve_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n,
         return;
     }
     if (nb == 0) return;                   // the same in every thread
-    if (nb > (uint32_t)RB_CAP) nb = RB_CAP;                         // (cannot be: C_BOVF would be set)
+    if (nb > w.bcap) nb = w.bcap;                                   // (cannot be: C_BOVF would be set)
+    const uint64_t* bucket_keys = w.bkeys + (size_t)b * w.bcap;
+    if (FAT) {
+        // this sub-range's keys out of the bucket's (slot inside the bucket's range >> bsubshift names the sub-range)
+        const uint32_t nb_all = nb;
+        if (tix == 0) sub_n = 0;
+        __syncthreads();
+        for (uint32_t e = tix; e < nb_all; e += RB_T) {
+            const uint64_t kv = bucket_keys[e];
+            if ((uint32_t)(kv >> 35) >> w.bsubshift == sub) {
+                const uint32_t at = atomicAdd(&sub_n, 1u);
+                if (at < (uint32_t)RB_CAP) kbuf[at] = kv;
+            }
+        }
+        __syncthreads();
+        nb = sub_n;
+        if (nb == 0) return;               // the same in every thread
+        if (nb > (uint32_t)RB_CAP) {
+            // too many for the LDS: chain them on their slots instead; the long-chain pass takes every touched barrier
+            for (uint32_t e0 = 0; e0 < nb_all; e0 += RB_T) {          // uniform: wave_append below
+                const uint32_t e = e0 + tix;
+                bool first = false;
+                uint32_t s = 0;
+                if (e < nb_all) {
+                    const uint64_t kv = bucket_keys[e];
+                    if ((uint32_t)(kv >> 35) >> w.bsubshift == sub) {
+                        const uint32_t i = bkey_event(kv);
+                        s = (b << w.bshift) | (uint32_t)(kv >> 35);
+                        const uint32_t prev = a_xchg(&t.slots[s].chain, i + 1);
+                        w.node[i] = node_pack(prev, (uint32_t)kv & 1023u, (kv & 1024u) ? recs[i].max_wait_s : 0u);
+                        first = prev == 0;
+                    }
+                }
+                const uint32_t at = wave_append(&w.counters[C_COMPLEX], first);
+                if (first) w.complex_[at] = s;
+            }
+            return;
+        }
+    }
     for (uint32_t c = tix; c < (uint32_t)RB_H; c += RB_T) { hkey[c] = 0; hhead[c] = 0; }
-    for (uint32_t e = tix; e < nb; e += RB_T) kbuf[e] = w.bkeys[(size_t)b * RB_CAP + e];
+    if (!FAT)
+        for (uint32_t e = tix; e < nb; e += RB_T) kbuf[e] = bucket_keys[e];
     __syncthreads();
     for (uint32_t e = tix; e < nb; e += RB_T) {
         const uint32_t sl = (uint32_t)(kbuf[e] >> 35);
@@ -717,7 +767,7 @@ join_resolve_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n,
                 completed = replay_short_chain<CHAIN_REG>(t, w, s, info, bits0, idx, nd, m, now, status);
             }
         }
-        ready_append_wave(t, completed, s, b * (RB_T / 64) + (tix >> 6) + (e0 / RB_T));
+        ready_append_wave(t, completed, s, blk * (RB_T / 64) + (tix >> 6) + (e0 / RB_T));
         const uint32_t at = wave_append(&w.counters[C_COMPLEX], is_complex);
         if (is_complex) w.complex_[at] = s;
     }

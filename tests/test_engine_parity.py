@@ -140,20 +140,26 @@ def test_thousands_of_barriers_with_ten_events_a_batch(oracle_lib, hot_mode):
         e.close()
 
 
-@pytest.mark.parametrize("hot_mode,n", [(-1, 1_200_000), (16, 1_200_000), (16, 400_000), (16, 700_000)])
+@pytest.mark.parametrize("hot_mode,n", [(-1, 1_200_000), (16, 1_200_000), (16, 400_000), (16, 700_000),
+                                        (16, 1_500_000), (-1, 2_000_000), (16, 3_000_000)])
 def test_batch_a_little_above_a_million_events(oracle_lib, hot_mode, n):
     """1.2 M events in one batch on 300 000 barriers (a rank of a routed job with 2^20 events per rank receives a
     little more or less than 2^20): the bucketed passes hold up to 1280 events per bucket on average.  Statuses
     element by element, then the stored state of a sample of the barriers.  The smaller batches make tiles of two
-    and three rounds in the first pass (1.2 M: 512 tiles of three)."""
+    and three rounds in the first pass (1.2 M: 512 tiles of three).  Above 1024 x 1280 events a bucket holds the
+    keys of two or four sub-ranges of its slots, which the second pass takes one after the other (1.5 M and 2 M:
+    two, 3 M: four)."""
     rng = np.random.default_rng(77)
     nb = 300_000
     ids = [f"big{b:x}~t{b:x}" for b in range(nb)]
     counts = rng.integers(2, 10, nb)
-    e, o, d = make_pair(oracle_lib, ids, 64, max_count=16, arena=1 << 30, max_batch=1 << 21, hot_mode=hot_mode)
+    e, o, d = make_pair(oracle_lib, ids, 64, max_count=16, arena=1 << 30, max_batch=1 << (22 if n > 1 << 21 else 21),
+                        hot_mode=hot_mode)
     try:
         now = T0 + 5
-        d.fork(np.arange(nb), counts, np.full(nb, now + 60_000))
+        for lo in range(0, nb, 1 << 16):
+            idx = np.arange(lo, min(lo + (1 << 16), nb))
+            d.fork(idx, counts[idx], np.full(len(idx), now + 60_000))
         for r in range(2):
             now += 7
             jb = rng.integers(0, nb + 1000, n) % nb
