@@ -553,7 +553,7 @@ def main():
         # measured streaming ceiling of this GPU beside the spec peak: the library's own 16-bytes-per-lane HIP copy kernel
         # over 1 GiB (dj_measure_copy), and what the hardware guide measured for such a copy on this chip
         roofline["measured_copy_GBps"] = round(eng.measure_copy(1 << 30, 5), 1) if hasattr(eng.L, "dj_measure_copy") else None    # (an older build under A/B lacks it)
-        roofline["measured_copy_kernel"] = "dj_measure_copy: uint4 per lane, 4 loads in flight, 8 blocks of 256 per CU, 1 GiB, read + written bytes"
+        roofline["measured_copy_kernel"] = "dj_measure_copy: one uint4 load and store per lane, the grid covers the buffer (the fastest of the shapes in tools/copy_sweep.hip), 1 GiB, read + written bytes"
         roofline["peak_achievable"] = HBM_ACHIEVABLE_GBPS
         # the whole join path (link + resolve + copy) against its per-event figure 112 + 2P
         jt = sum(kernels[k]["avg_ms"] for k in ("join_link", "join_resolve", "join_complex", "join_copy") if k in kernels)

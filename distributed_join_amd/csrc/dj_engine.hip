@@ -1365,7 +1365,8 @@ extern "C" int dj_measure_copy(dj_engine* e, uint64_t bytes, uint32_t iterations
         HIP_TRY(e, hipMemsetAsync(src, 1, bytes, e->stream));
         HIP_TRY(e, hipEventCreate(&a));
         HIP_TRY(e, hipEventCreate(&b));
-        const uint32_t blocks = e->n_cus * 8;
+        if (bytes / 16 / 256 >= 0x7FFFFFFFull) return fail(e, DJ_E_INVALID, "measure_copy: %llu bytes are more than one launch covers", (unsigned long long)bytes);
+        const uint32_t blocks = (uint32_t)((bytes / 16 + 255) / 256);
         stream_copy_kernel<<<blocks, 256, 0, e->stream>>>((const uint4*)src, (uint4*)dst, bytes / 16);      // warm-up
         HIP_TRY(e, hipEventRecord(a, e->stream));
         for (uint32_t k = 0; k < iterations; ++k) stream_copy_kernel<<<blocks, 256, 0, e->stream>>>((const uint4*)src, (uint4*)dst, bytes / 16);

@@ -2460,16 +2460,13 @@ __global__ void __launch_bounds__(256) scatter_statuses_kernel(uint32_t n, const
         out[origin[j]] = sorted[j];
 }
 
-// Measurement aid: a plain streaming copy, 16 bytes per lane, four loads in flight per thread before the first store.
+// Measurement aid: a plain streaming copy, one 16-byte load and store per lane, no loop: the grid covers the buffer.
 // What this GPU's memory delivers to the simplest possible kernel is the ceiling the byte-moving passes are held against.
+// (Of the shapes tools/copy_sweep.hip tries on 1 GiB this one is the fastest, 6.2 TB/s read + written; a grid-stride loop
+// with four loads in flight per lane reaches 4.1 to 4.7, chunks of 4 x 256 lanes per block 5.4 to 5.9.)
 __global__ void __launch_bounds__(256) stream_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, uint64_t n16) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-    }
-    for (; i < n16; i += stride) dst[i] = src[i];
+    const uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
 }
 
 }  // namespace dj
