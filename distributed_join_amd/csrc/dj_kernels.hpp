@@ -159,7 +159,7 @@ constexpr int LINK_BLOCK = 512, LINK_BLOCK_HOT = 1024;
 // Copies the message of one event into its row, G lanes per message (wave-cooperative: the event's lane hands
 // its source and destination to the G lanes that move it).  The row is written in whole 64-byte lines
 // (zeros behind the message): a partly written line costs a read-modify-write in memory.
-template <int G>
+template <int G, int STEP_FROM = 0>
 __device__ inline void wave_copy_rows(const Table& t, const uint8_t* payloads, uint64_t pitch, uint64_t ev0, uint64_t row_off,
                                       uint32_t len) {
     constexpr int EPS = 64 / G;                     // events per step
@@ -169,7 +169,7 @@ __device__ inline void wave_copy_rows(const Table& t, const uint8_t* payloads, u
     // issued before the first store, so a wave waits for memory once per four rows instead of once per row.
     constexpr int FLIGHT = 4;
 #pragma unroll 1
-    for (int step0 = 0; step0 < G; step0 += FLIGHT) {
+    for (int step0 = STEP_FROM; step0 < G; step0 += FLIGHT) {
         uint4 v[FLIGHT];
         uint4* to[FLIGHT];
         bool on[FLIGHT];
@@ -187,6 +187,38 @@ __device__ inline void wave_copy_rows(const Table& t, const uint8_t* payloads, u
 #pragma unroll
         for (int f = 0; f < FLIGHT; ++f)
             if (on[f]) nt_store(to[f], v[f]);
+    }
+}
+
+// The same copy in two halves, for a caller that knows where a message comes from before it knows where it goes: the
+// loads of steps step0 .. step0 + 3 (len_pre: the message's length where it may be read at all, else 0), and their
+// stores once the rows are known (row_off = ~0: no row; len as in wave_copy_rows).  What is in flight between the two
+// calls overlaps whatever the caller does there (the table probe).
+template <int G>
+__device__ inline void wave_rows_load(const uint8_t* payloads, uint64_t pitch, uint64_t ev0, uint32_t len_pre, int step0, uint4 (&v)[4]) {
+    constexpr int EPS = 64 / G;
+    const uint32_t lane = threadIdx.x & 63, sub = lane / G, j0 = lane % G;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int src = (step0 + f) * EPS + (int)sub;
+        const uint32_t ln = __shfl(len_pre, src);
+        v[f] = make_uint4(0, 0, 0, 0);
+        if (j0 < ((ln + 15) >> 4)) v[f] = nt_load(&reinterpret_cast<const uint4*>(payloads + (ev0 + (uint64_t)src) * pitch)[j0]);
+    }
+}
+template <int G>
+__device__ inline void wave_rows_store(const Table& t, uint64_t row_off, uint32_t len, int step0, const uint4 (&v)[4]) {
+    constexpr int EPS = 64 / G;
+    const uint32_t lane = threadIdx.x & 63, sub = lane / G, j0 = lane % G;
+    const uint32_t rlo = (uint32_t)row_off, rhi = (uint32_t)(row_off >> 32);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int src = (step0 + f) * EPS + (int)sub;
+        const uint64_t row = ((uint64_t)__shfl(rhi, src) << 32) | __shfl(rlo, src);
+        const uint32_t ln = __shfl(len, src);
+        const uint32_t chunks = (ln + 15) >> 4, full = (chunks + 3) & ~3u;
+        if (row != ~0ull && j0 < full)
+            nt_store(reinterpret_cast<uint4*>(t.arena + row) + j0, j0 < chunks ? v[f] : make_uint4(0, 0, 0, 0));
     }
 }
 
@@ -524,7 +556,7 @@ __device__ inline uint32_t bkey_event(uint64_t k) { return (uint32_t)(k >> 11) &
 // the GPU holds at once, or one longer than the others, costs a whole extra round), and a tile still holds two to four
 // keys per bucket.  Round k of a tile takes its events k * 1024 .. k * 1024 + 1023.
 template <int G, int EPT>
-__global__ void __launch_bounds__(BK_BLOCK) __attribute__((amdgpu_waves_per_eu(8)))
+__global__ void __launch_bounds__(BK_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 8)))
 join_link_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, uint32_t tile_events, uint64_t pitch, int32_t* status,
                         const uint8_t* payloads) {
     const uint32_t tile_base = blockIdx.x * tile_events;
@@ -549,6 +581,20 @@ join_link_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, ui
     uint64_t key[EPT];
     uint32_t bk[EPT], rank[EPT];
     bool linked[EPT];
+    // all records of the thread first (they are where the array says), then per event: its message's loads, the table
+    // probe while those are in flight, the stores
+    ulonglong2 ra[EPT];
+    uint4 rb[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const uint32_t i = tile_base + k * BK_BLOCK + tix;
+        ra[k] = make_ulonglong2(0, 0);
+        rb[k] = make_uint4(0, 0, 0, 0);
+        if (i < tile_end) {
+            ra[k] = reinterpret_cast<const ulonglong2*>(recs)[2 * (size_t)i];
+            rb[k] = reinterpret_cast<const uint4*>(recs)[2 * (size_t)i + 1];      // position, len, max_wait, -
+        }
+    }
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
         const uint32_t i = tile_base + k * BK_BLOCK + tix;
@@ -556,9 +602,11 @@ join_link_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, ui
         uint32_t row_len = 0;
         bool stores_meta = false;
         key[k] = 0; bk[k] = 0; rank[k] = 0; linked[k] = false;
+        const ulonglong2 a = ra[k];
+        const uint4 b = rb[k];
+        uint4 pv[4];
+        wave_rows_load<G>(payloads, pitch, (uint64_t)i - lane, (i < tile_end && b.y <= t.max_message && b.y <= pitch) ? b.y : 0u, 0, pv);
         if (i < tile_end) {
-            const ulonglong2 a = reinterpret_cast<const ulonglong2*>(recs)[2 * (size_t)i];
-            const uint4 b = reinterpret_cast<const uint4*>(recs)[2 * (size_t)i + 1];  // position, len, max_wait, -
             int32_t st = 0;
             int64_t s = -1;
             uint4 info = make_uint4(0, 0, 0, 0);
@@ -591,7 +639,8 @@ join_link_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, ui
                 rank[k] = atomicAdd(&hist[bk[k]], 1u);
             }
         }
-        wave_copy_rows<G>(t, payloads, pitch, (uint64_t)i - lane, row_off, row_len);
+        wave_rows_store<G>(t, row_off, row_len, 0, pv);
+        if constexpr (G > 4) wave_copy_rows<G, 4>(t, payloads, pitch, (uint64_t)i - lane, row_off, row_len);
         // a sample for the host: how ragged is the traffic (the batch's first 4 x 64 events)
         if (blockIdx.x == 0 && k == 0 && wave < 4 && w.publish_hints) {
             const uint64_t m = __ballot(stores_meta);
