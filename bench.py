@@ -274,6 +274,14 @@ def run_config3(torch, capi, Engine, dev, local, nb):
 
 def main():
     a = parse()
+    # the one JSON line is all that may appear on stdout: libraries that write there (RCCL prints its version banner when
+    # the first communicator comes up) are sent to stderr for the length of the run
+    # (a caller that has put its own file object in sys.stdout gets the line there)
+    sys.stdout.flush()
+    json_fd = None
+    if sys.stdout is sys.__stdout__:
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from distributed_join_amd import capi
@@ -607,7 +615,11 @@ def main():
             "gpu_stream_ms": gpu_ms, "host_issue_ms_per_step": issue * 1e3 / timed_steps,
             "roofline": roofline, "kernels": kernels, "cpu_baseline": cpu, "config3": c3,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        if json_fd is not None:
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+        else:
+            print(json.dumps(out))
     if routed:
         dist.destroy_process_group()
     if eng is not None:
