@@ -14,9 +14,9 @@ T0 = 1_700_000_000_000
 NB, COUNT, PITCH = 6000, 8, 64
 
 
-def _engine():
+def _engine(max_batch=1 << 17):
     from distributed_join_amd.engine import Engine
-    return Engine(capacity_barriers=NB, arena_bytes=64 << 20, max_count=64, payload_stride=64, max_batch=1 << 17,
+    return Engine(capacity_barriers=NB, arena_bytes=64 << 20, max_count=64, payload_stride=64, max_batch=max_batch,
                   host_cap_conts=NB + 8, host_cap_positions=(NB + 8) * 64)
 
 
@@ -103,6 +103,72 @@ def test_static_join_matches_join_batch_two_calls_in_a_row():
         assert bytes(rp[p][:k]) == bytes(sp[p][:k]), p
     ref.close()
     sta.close()
+
+
+def _forked_pair(prefix, static_max_batch=1 << 17):
+    """(fingerprints, engine for dj_join_batch, engine for dj_join_batch_static), both with the same NB barriers."""
+    ids = [f"{prefix}{k:x}~t{k:x}" for k in range(NB)]
+    fps = capi.fingerprint_many(ids)
+    forks = np.zeros(NB, dtype=capi.FORK_REC)
+    forks["fp_lo"], forks["fp_hi"], forks["count"], forks["deadline_ms"] = fps[:, 0], fps[:, 1], COUNT, T0 + 3_600_000
+    forks["count"][7] = 64
+    ref, sta = _engine(), _engine(static_max_batch)
+    for e in (ref, sta):
+        for lo in range(0, NB, 4096):             # (an engine with a small max_batch takes its forks in pieces)
+            assert (e.fork_batch(forks[lo:lo + 4096]) == capi.DJ_FORK_CREATED).all()
+    return fps, ref, sta
+
+
+def _static_call_equals_plain(fps, ref, sta, rng, n, version, now):
+    import torch
+    b, pos, length, mw, unknown, pay = _events(rng, n, version)
+    recs = _recs(fps, b, pos, length, mw, unknown)
+    want = ref.join_batch(recs, pay, now)
+    d_recs, d_pay, d_st = to_device(recs, sta.device), to_device(pay, sta.device), sta.empty(n * 4)
+    torch.cuda.synchronize()                      # nothing of another engine's call is still running on this GPU
+    sta.join_batch_static_dev(n, d_recs, d_pay, PITCH, now, d_st)
+    sta.sync()
+    got = from_device(d_st, np.int32, n)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, f"statuses differ at {bad[:8]}: static {got[bad[:8]]} plain {want[bad[:8]]}"
+
+
+def test_static_join_on_an_engine_whose_own_batches_are_smaller():
+    """The static path brings its own work arrays: its limit is DJ_STATIC_JOIN_MAX, whatever max_batch the engine's own
+    arrays were sized for (here 4096 events against calls of 30 000 and 65 536)."""
+    fps, ref, sta = _forked_pair("m", static_max_batch=4096)
+    rng = np.random.default_rng(5)
+    now = T0
+    for call, n in enumerate((30000, capi.DJ_STATIC_JOIN_MAX, 777)):
+        now += 5
+        _static_call_equals_plain(fps, ref, sta, rng, n, call, now)
+    _, rcanon = _sweep_canon(ref, now)
+    _, scanon = _sweep_canon(sta, now)
+    assert len(rcanon) > 300 and rcanon == scanon, "popped continuations differ"
+    with pytest.raises(EngineError, match="exceeds max_batch=4096"):
+        sta.join_batch(np.zeros(5000, dtype=capi.JOIN_REC), np.zeros((5000, PITCH), np.uint8), now)   # the plain path keeps its own limit
+    ref.close()
+    sta.close()
+
+
+def test_two_engines_on_one_gpu_take_turns_on_the_static_array():
+    """The array belongs to the GPU, not to an engine: two engines that call one after the other (never at the same time)
+    each find the other's leftovers in it, larger and smaller than their own batch."""
+    fa, ref_a, sta_a = _forked_pair("a")
+    fb, ref_b, sta_b = _forked_pair("b")
+    rng = np.random.default_rng(6)
+    now = T0
+    turns = [(fa, ref_a, sta_a, 40000), (fb, ref_b, sta_b, 9000), (fa, ref_a, sta_a, 3000), (fb, ref_b, sta_b, 65000),
+             (fa, ref_a, sta_a, 20000)]
+    for call, (fps, ref, sta, n) in enumerate(turns):
+        now += 5
+        _static_call_equals_plain(fps, ref, sta, rng, n, call, now)
+    for ref, sta in ((ref_a, sta_a), (ref_b, sta_b)):
+        _, rcanon = _sweep_canon(ref, now + 3_600_001)
+        _, scanon = _sweep_canon(sta, now + 3_600_001)
+        assert len(rcanon) > 1000 and rcanon == scanon
+        ref.close()
+        sta.close()
 
 
 def test_static_join_refuses_more_than_its_limit():
