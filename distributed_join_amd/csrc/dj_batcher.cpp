@@ -142,7 +142,7 @@ struct dj_batcher {
     uint8_t* d_jpay = nullptr;
     dj_fork_rec* d_frecs = nullptr;
     int32_t* d_status = nullptr;
-    int32_t* h_status = nullptr;     // pinned, max_batch
+    int32_t* h_status = nullptr;     // pinned, 2 x max_batch (fork answers, join answers)
     dj_batcher_stats stats{};
     int fatal = 0;                   // first engine error seen by the drain thread; answers carry it as status
     dj_router* router = nullptr;     // routed form: this rank's router (d_status then holds the answers that came home)
@@ -198,34 +198,62 @@ void answer_all(dj_batcher* b, uint32_t n, int rc) {
     for (uint32_t i = 0; i < n; ++i) b->ans[i].cb(b->ans[i].user, rc == DJ_OK ? b->h_status[i] : rc);
 }
 
-// one window: phases of (fork batch, join batch), each in engine calls of at most max_batch records
+// Batches of at most this many records are read by the kernels where the drain thread staged them (pinned host memory
+// that the device maps) and answered into pinned memory as well: three small copies per batch cost more than a few
+// hundred kilobytes read over the host link.  Larger batches go through device buffers as before.
+constexpr uint32_t ZERO_COPY_MAX = 2048;
+
+// one window: phases of (fork batch, join batch), each in engine calls of at most max_batch records.  The forks of a
+// phase are answered together with its joins, after ONE wait for the stream (fork statuses in h_status[0, mb), join
+// statuses in h_status[mb, 2 mb)).
 void apply(dj_batcher* b, Window& w, uint64_t now, std::vector<Waiter*>& waiters) {
     hipStream_t st = static_cast<hipStream_t>(dj_stream(b->e));
     const uint32_t mb = b->cfg.max_batch;
     int rc = b->fatal;
     uint64_t largest = 0, calls = 0;
-    auto flush_forks = [&](uint32_t n) {
-        if (!n) return;
-        if (rc == DJ_OK && !hip_ok(hipMemcpyAsync(b->d_frecs, b->h_frecs, (size_t)n * sizeof(dj_fork_rec), hipMemcpyHostToDevice, st))) rc = DJ_E_HIP;
-        if (rc == DJ_OK) rc = dj_fork_batch(b->e, n, b->d_frecs, b->d_status);
-        if (rc == DJ_OK && !hip_ok(hipMemcpyAsync(b->h_status, b->d_status, (size_t)n * 4, hipMemcpyDeviceToHost, st))) rc = DJ_E_HIP;
+    uint32_t forks_pending = 0;            // fork records launched whose answers wait for the next stream wait
+    auto wait_and_answer = [&](uint32_t nf, uint32_t nj) {
         if (rc == DJ_OK) rc = dj_sync(b->e);
-        answer_all(b, n, rc);
+        for (uint32_t i = 0; i < nf; ++i) b->ans[i].cb(b->ans[i].user, rc == DJ_OK ? b->h_status[i] : rc);
+        for (uint32_t i = 0; i < nj; ++i) b->ans[mb + i].cb(b->ans[mb + i].user, rc == DJ_OK ? b->h_status[mb + i] : rc);
+        forks_pending = 0;
+    };
+    auto flush_forks = [&](uint32_t n, bool joins_follow) {
+        if (!n) return;
+        if (n <= ZERO_COPY_MAX) {
+            if (rc == DJ_OK) rc = dj_fork_batch(b->e, n, b->h_frecs, b->h_status);
+        } else {
+            if (rc == DJ_OK && !hip_ok(hipMemcpyAsync(b->d_frecs, b->h_frecs, (size_t)n * sizeof(dj_fork_rec), hipMemcpyHostToDevice, st))) rc = DJ_E_HIP;
+            if (rc == DJ_OK) rc = dj_fork_batch(b->e, n, b->d_frecs, b->d_status);
+            if (rc == DJ_OK && !hip_ok(hipMemcpyAsync(b->h_status, b->d_status, (size_t)n * 4, hipMemcpyDeviceToHost, st))) rc = DJ_E_HIP;
+        }
+        forks_pending = n;
+        if (!joins_follow) wait_and_answer(n, 0);
         if (n > largest) largest = n;
         ++calls;
     };
     auto flush_joins = [&](uint32_t n) {
         if (!n) return;
-        if (rc == DJ_OK && !hip_ok(hipMemcpyAsync(b->d_jrecs, b->h_jrecs, (size_t)n * sizeof(dj_join_rec), hipMemcpyHostToDevice, st))) rc = DJ_E_HIP;
-        if (rc == DJ_OK && !hip_ok(hipMemcpyAsync(b->d_jpay, b->h_jpay, (size_t)n * b->pitch, hipMemcpyHostToDevice, st))) rc = DJ_E_HIP;
-        if (rc == DJ_OK) rc = dj_join_batch(b->e, n, b->d_jrecs, b->d_jpay, b->pitch, now, b->d_status);
-        if (rc == DJ_OK && !hip_ok(hipMemcpyAsync(b->h_status, b->d_status, (size_t)n * 4, hipMemcpyDeviceToHost, st))) rc = DJ_E_HIP;
-        if (rc == DJ_OK) rc = dj_sync(b->e);
-        answer_all(b, n, rc);
+        if (n <= ZERO_COPY_MAX) {
+            if (rc == DJ_OK) rc = dj_join_batch(b->e, n, b->h_jrecs, b->h_jpay, b->pitch, now, b->h_status + mb);
+        } else {
+            if (rc == DJ_OK && !hip_ok(hipMemcpyAsync(b->d_jrecs, b->h_jrecs, (size_t)n * sizeof(dj_join_rec), hipMemcpyHostToDevice, st))) rc = DJ_E_HIP;
+            if (rc == DJ_OK && !hip_ok(hipMemcpyAsync(b->d_jpay, b->h_jpay, (size_t)n * b->pitch, hipMemcpyHostToDevice, st))) rc = DJ_E_HIP;
+            if (rc == DJ_OK) rc = dj_join_batch(b->e, n, b->d_jrecs, b->d_jpay, b->pitch, now, b->d_status);
+            if (rc == DJ_OK && !hip_ok(hipMemcpyAsync(b->h_status + mb, b->d_status, (size_t)n * 4, hipMemcpyDeviceToHost, st))) rc = DJ_E_HIP;
+        }
+        wait_and_answer(forks_pending, n);
         if (n > largest) largest = n;
         ++calls;
     };
     for (uint32_t p = 0; p < w.phases; ++p) {
+        // does this phase hold joins?  (then its last fork batch is answered with them)
+        bool phase_joins = false;
+        for (int k = 0; k < w.n && !phase_joins; ++k) {
+            uint32_t from, to;
+            phase_range(w.side[k]->cut_j, w.side[k]->jrecs.size(), p, &from, &to);
+            phase_joins = to > from;
+        }
         uint32_t n = 0;
         for (int k = 0; k < w.n; ++k) {
             LaneSide& s = *w.side[k];
@@ -235,10 +263,10 @@ void apply(dj_batcher* b, Window& w, uint64_t now, std::vector<Waiter*>& waiters
                 b->h_frecs[n] = s.frecs[i];
                 b->ans[n] = s.fans[i];
                 if (s.fans[i].cb == wait_cb) waiters.push_back(static_cast<Waiter*>(s.fans[i].user));
-                if (++n == mb) { flush_forks(n); n = 0; }
+                if (++n == mb) { flush_forks(n, false); n = 0; }
             }
         }
-        flush_forks(n);
+        flush_forks(n, phase_joins);
         n = 0;
         for (int k = 0; k < w.n; ++k) {
             LaneSide& s = *w.side[k];
@@ -247,12 +275,13 @@ void apply(dj_batcher* b, Window& w, uint64_t now, std::vector<Waiter*>& waiters
             for (uint32_t i = from; i < to; ++i) {
                 b->h_jrecs[n] = s.jrecs[i];
                 if (s.jrecs[i].len) memcpy(b->h_jpay + (size_t)n * b->pitch, s.bytes.data() + s.joff[i], s.jrecs[i].len);
-                b->ans[n] = s.jans[i];
+                b->ans[mb + n] = s.jans[i];
                 if (s.jans[i].cb == wait_cb) waiters.push_back(static_cast<Waiter*>(s.jans[i].user));
                 if (++n == mb) { flush_joins(n); n = 0; }
             }
         }
         flush_joins(n);
+        if (forks_pending) wait_and_answer(forks_pending, 0);      // (cannot be: a phase with joins flushes them last)
     }
     if (rc != DJ_OK && !b->fatal) b->fatal = rc;
     std::lock_guard<std::mutex> g(b->mu);
@@ -545,12 +574,12 @@ static int batcher_create(dj_engine* e, dj_router* router, const dj_batcher_conf
     ok = ok && hip_ok(hipHostMalloc((void**)&b->h_jrecs, mb * sizeof(dj_join_rec), hipHostMallocDefault));
     ok = ok && hip_ok(hipHostMalloc((void**)&b->h_jpay, mb * b->pitch, hipHostMallocDefault));
     ok = ok && hip_ok(hipHostMalloc((void**)&b->h_frecs, mb * sizeof(dj_fork_rec), hipHostMallocDefault));
-    b->ans.resize(mb);
+    b->ans.resize(2 * (size_t)mb);           // forks [0, mb), joins [mb, 2 mb)
     ok = ok && hip_ok(hipMalloc((void**)&b->d_jrecs, mb * sizeof(dj_join_rec)));
     ok = ok && hip_ok(hipMalloc((void**)&b->d_jpay, mb * b->pitch));
     ok = ok && hip_ok(hipMalloc((void**)&b->d_frecs, mb * sizeof(dj_fork_rec)));
     ok = ok && hip_ok(hipMalloc((void**)&b->d_status, mb * 4));
-    ok = ok && hip_ok(hipHostMalloc((void**)&b->h_status, mb * 4, hipHostMallocDefault));
+    ok = ok && hip_ok(hipHostMalloc((void**)&b->h_status, 2 * (size_t)mb * 4, hipHostMallocDefault));
     if (!ok) {
         dj_batcher_destroy(b);
         return DJ_E_NOMEM;
