@@ -172,6 +172,35 @@ def test_batch_a_little_above_a_million_events(oracle_lib, hot_mode, n):
         e.close()
 
 
+@pytest.mark.parametrize("hot_events", [2300, 6000])
+def test_hot_barrier_inside_a_batch_of_fat_buckets(oracle_lib, hot_events):
+    """1.5 M events in the bucketed form (two sub-ranges per bucket), one barrier with thousands of them and no earlier
+    batch to warn of it.  2300: its sub-range passes the 2048 keys a block holds while its bucket stays within 4096 (that
+    sub-range's events are chained on their slots for the long-chain pass, every other sub-range replays as usual);
+    6000: the bucket itself overflows and the whole batch falls back to chains.  Statuses element by element, then the
+    hot barrier's and a sample of the others' stored state."""
+    rng = np.random.default_rng(91)
+    nb, n = 300_000, 1_500_000
+    ids = [f"fat{b:x}~t{b:x}" for b in range(nb)]
+    counts = rng.integers(2, 10, nb)
+    counts[5] = 9
+    e, o, d = make_pair(oracle_lib, ids, 64, max_count=16, arena=1 << 30, max_batch=1 << 21, hot_mode=16)
+    try:
+        now = T0 + 5
+        d.fork(np.arange(nb), counts, np.full(nb, now + 60_000))
+        for r in range(2):
+            now += 7
+            jb = rng.integers(0, nb, n)
+            jb[rng.choice(n, hot_events, replace=False)] = 5
+            pos = (rng.random(n) * counts[jb]).astype(np.int64)
+            pos[jb == 5] = rng.integers(0, 8, int((jb == 5).sum()))      # position 8 stays open: the barrier never completes
+            jmw = np.where(rng.random(n) < 0.1, rng.integers(1, 5, n), 0)
+            d.join(jb, pos, np.full(n, 64), jmw, payload_bytes(jb, pos % 1024, np.full(n, r + 1) + np.arange(n), 64), now)
+        d.check_all_snapshots(which=np.concatenate([[5], rng.choice(nb, 1000, replace=False)]))
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("hot_mode", [-1, 0, 1, 4, 16])
 def test_hot_barrier_long_chains(oracle_lib, hot_mode):
     rng = np.random.default_rng(2)
