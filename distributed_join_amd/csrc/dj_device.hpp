@@ -204,6 +204,7 @@ struct Work {
     uint32_t bcap;                // keys a bucket holds (bfat x the second pass's LDS capacity)
     uint32_t bfat;                // sub-ranges the second pass cuts a bucket's slot range into (1: the bucket fits its LDS)
     uint32_t bsubshift;           // sub-range of a key = its slot inside the bucket's range >> bsubshift
+    uint32_t bmwbits;             // bits of a key above its slot field that carry a short max-wait (0: none)
 };
 constexpr uint32_t SLOT_CREATED = 0x80000000u;      // tables have at most 2^30 slots
 enum { C_COMPLEX = 1, C_MAXCHAIN = 2, C_CXPOOL = 3, C_MID = 4, C_RECOPY = 5, C_BOVF = 6, C_COUNT = 8 };    // C_BOVF: a bucket overflowed

@@ -318,7 +318,7 @@ static int create_impl(dj_engine* e) {
     ALLOC(e, w.bkeys, (size_t)BK_MAX_BUCKETS * RB_CAP * e->bfat_max * 8);
     ALLOC(e, w.bcursor, BK_MAX_BUCKETS * 4);
     HIP_TRY(e, hipMemsetAsync(w.bcursor, 0, BK_MAX_BUCKETS * 4, e->stream));
-    w.bbuckets = w.bshift = w.bsubshift = 0;
+    w.bbuckets = w.bshift = w.bsubshift = w.bmwbits = 0;
     w.bcap = RB_CAP;
     w.bfat = 1;
     ALLOC(e, w.cx_keys, CX_HASH * 4);
@@ -657,6 +657,7 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
         w.bfat = fat;
         w.bcap = fat * RB_CAP;
         w.bsubshift = shift - fat_log;
+        w.bmwbits = shift >= 29 ? 0u : (29 - shift > 14 ? 14u : 29 - shift);
         bucket = (uint64_t)B * BK_MEAN_MAX * fat >= n;        // (a tiny table cannot spread a large batch)
     }
     // equal tiles of the first pass: one per compute unit (two above 4096 events per unit; a unit holds two blocks),

@@ -545,9 +545,18 @@ join_resolve_kernel(Table t, Work w, uint32_t n, uint64_t now, int32_t* status) 
 constexpr int BK_TILE = 4096, BK_BLOCK = 1024, BK_MAX_BUCKETS = 1024;      // BK_TILE: the largest tile (four events per thread)
 constexpr uint32_t BK_MEAN_MAX = 1280;     // events per bucket on average at most (a bucket holds RB_CAP; a batch of random keys spreads with a deviation of about 36)
 constexpr int RB_T = 512, RB_EPT = 4, RB_CAP = RB_T * RB_EPT, RB_H = RB_CAP;    // (as many cells as keys at most: a free cell is always left for a new slot)
-// key: slot inside its bucket's range << 35 | event index (24 bits) << 11 | has-max-wait << 10 | position (10 bits)
-__device__ inline uint64_t bkey_pack(uint32_t slot_local, uint32_t i, uint32_t pos, bool has_mw) {
-    return ((uint64_t)slot_local << 35) | ((uint64_t)i << 11) | (has_mw ? 1024u : 0u) | pos;
+// key: [max-wait, M bits] slot inside its bucket's range << 35 | event index (24 bits) << 11 | has-max-wait << 10 | position (10 bits)
+// M = Work::bmwbits: the bits above the slot field that the bucket's range leaves free (0 to 14).  A max-wait below 2^M
+// travels in the key; a longer one (or M = 0) leaves the field 0 and the second pass reads it from the event's record.
+__device__ inline uint64_t bkey_pack(uint32_t slot_local, uint32_t i, uint32_t pos, uint32_t mw, uint32_t M) {
+    const uint64_t inl = (M != 0 && mw < (1u << M)) ? ((uint64_t)mw << (64 - M)) : 0ull;     // (mw = 0: nothing to carry)
+    return inl | ((uint64_t)slot_local << 35) | ((uint64_t)i << 11) | (mw ? 1024u : 0u) | pos;
+}
+__device__ inline uint32_t bkey_slot(uint64_t k, uint32_t M) { return (uint32_t)((k << M) >> (35 + M)); }
+__device__ inline uint32_t bkey_mw(uint64_t k, uint32_t M, const dj_join_rec* recs, uint32_t i) {
+    if (!(k & 1024u)) return 0u;
+    const uint32_t inl = M ? (uint32_t)(k >> (64 - M)) : 0u;
+    return inl ? inl : recs[i].max_wait_s;
 }
 __device__ inline uint32_t bkey_event(uint64_t k) { return (uint32_t)(k >> 11) & 0xFFFFFFu; }
 
@@ -633,7 +642,7 @@ join_link_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, ui
                 if (pm) slab_posmeta(t, info.z, kc)[b.x] = make_uint2(b.y, b.z);
                 const uint32_t slot = (uint32_t)s;
                 w.ev_slot[i] = slot;
-                key[k] = bkey_pack(slot & ((1u << shift) - 1), i, b.x, b.z != 0);
+                key[k] = bkey_pack(slot & ((1u << shift) - 1), i, b.x, b.z, w.bmwbits);
                 bk[k] = slot >> shift;
                 linked[k] = true;
                 rank[k] = atomicAdd(&hist[bk[k]], 1u);
@@ -729,7 +738,7 @@ join_resolve_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n,
         __syncthreads();
         for (uint32_t e = tix; e < nb_all; e += RB_T) {
             const uint64_t kv = bucket_keys[e];
-            if ((uint32_t)(kv >> 35) >> w.bsubshift == sub) {
+            if (bkey_slot(kv, w.bmwbits) >> w.bsubshift == sub) {
                 const uint32_t at = atomicAdd(&sub_n, 1u);
                 if (at < (uint32_t)RB_CAP) kbuf[at] = kv;
             }
@@ -745,11 +754,11 @@ join_resolve_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n,
                 uint32_t s = 0;
                 if (e < nb_all) {
                     const uint64_t kv = bucket_keys[e];
-                    if ((uint32_t)(kv >> 35) >> w.bsubshift == sub) {
+                    if (bkey_slot(kv, w.bmwbits) >> w.bsubshift == sub) {
                         const uint32_t i = bkey_event(kv);
-                        s = (b << w.bshift) | (uint32_t)(kv >> 35);
+                        s = (b << w.bshift) | bkey_slot(kv, w.bmwbits);
                         const uint32_t prev = a_xchg(&t.slots[s].chain, i + 1);
-                        w.node[i] = node_pack(prev, (uint32_t)kv & 1023u, (kv & 1024u) ? recs[i].max_wait_s : 0u);
+                        w.node[i] = node_pack(prev, (uint32_t)kv & 1023u, bkey_mw(kv, w.bmwbits, recs, i));
                         first = prev == 0;
                     }
                 }
@@ -764,7 +773,7 @@ join_resolve_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n,
         for (uint32_t e = tix; e < nb; e += RB_T) kbuf[e] = bucket_keys[e];
     __syncthreads();
     for (uint32_t e = tix; e < nb; e += RB_T) {
-        const uint32_t sl = (uint32_t)(kbuf[e] >> 35);
+        const uint32_t sl = bkey_slot(kbuf[e], w.bmwbits);
         uint32_t c = ((sl * 2654435761u) >> 19) & (RB_H - 1);
         for (;; c = (c + 1) & (RB_H - 1)) {
             const uint32_t old = atomicCAS(&hkey[c], 0u, sl + 1);
@@ -795,7 +804,7 @@ join_resolve_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n,
                 if (cur != 0) {
                     const uint64_t kv = kbuf[cur - 1];
                     idx[k] = bkey_event(kv);
-                    nd[k] = node_pack(0, (uint32_t)kv & 1023u, (kv & 1024u) ? recs[idx[k]].max_wait_s : 0u);
+                    nd[k] = node_pack(0, (uint32_t)kv & 1023u, bkey_mw(kv, w.bmwbits, recs, idx[k]));
                     cur = nxt[cur - 1];
                     ++m;
                 }
@@ -809,7 +818,7 @@ join_resolve_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n,
                     const uint64_t kv = kbuf[c2 - 1];
                     const uint32_t i = bkey_event(kv), nx = nxt[c2 - 1];
                     w.node[i] = node_pack(nx != 0 ? bkey_event(kbuf[nx - 1]) + 1 : 0u, (uint32_t)kv & 1023u,
-                                          (kv & 1024u) ? recs[i].max_wait_s : 0u);
+                                          bkey_mw(kv, w.bmwbits, recs, i));
                     c2 = nx;
                 }
             } else {

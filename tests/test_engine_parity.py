@@ -172,6 +172,36 @@ def test_batch_a_little_above_a_million_events(oracle_lib, hot_mode, n):
         e.close()
 
 
+@pytest.mark.parametrize("hot_mode", [-1, 16])
+def test_max_waits_short_and_long_in_one_batch(oracle_lib, hot_mode):
+    """Max-waits of seconds, hours and weeks in the same batches (the bucketed passes carry a short one in the event's
+    key and read a long one from its record): answers element by element, then sweeps at the dates the short ones
+    fall due, at the hours' and at the weeks'."""
+    rng = np.random.default_rng(313)
+    nb = 5000
+    ids = [f"mw{b:x}~t{b:x}" for b in range(nb)]
+    counts = rng.integers(2, 9, nb)
+    e, o, d = make_pair(oracle_lib, ids, 64, hot_mode=hot_mode, max_batch=1 << 17)
+    try:
+        now = T0 + 11
+        d.fork(np.arange(nb), counts, np.full(nb, now + 40 * 24 * 3_600_000))
+        choices = np.array([0, 0, 2, 3, 16383, 16384, 20_000, 5_000_000])
+        for r in range(3):
+            now += 40
+            n = 30_000
+            jb = rng.integers(0, nb, n)
+            pos = (rng.random(n) * counts[jb]).astype(np.int64)
+            pos[pos == counts[jb] - 1] = 0                   # the last position stays open: nothing completes
+            jmw = choices[rng.integers(0, len(choices), n)]
+            d.join(jb, pos, np.full(n, 64), jmw, payload_bytes(jb, pos, np.full(n, r + 1) + np.arange(n), 64), now)
+        for at in (now + 2_000, now + 3_000, now + 16_383_000, now + 16_384_000 + 80, now + 20_000_000 + 80, now + 5_000_000_000 + 80):
+            ec, oc = d.sweep(at)
+            d.ack(ec, oc, lambda k: True, at)
+        d.check_all_snapshots(range(0, nb, 50))
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("hot_events", [2300, 6000])
 def test_hot_barrier_inside_a_batch_of_fat_buckets(oracle_lib, hot_events):
     """1.5 M events in the bucketed form (two sub-ranges per bucket), one barrier with thousands of them and no earlier
