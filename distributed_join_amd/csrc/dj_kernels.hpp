@@ -600,8 +600,9 @@ join_link_bucket_kernel(Table t, Work w, const dj_join_rec* recs, uint32_t n, ui
         ra[k] = make_ulonglong2(0, 0);
         rb[k] = make_uint4(0, 0, 0, 0);
         if (i < tile_end) {
-            ra[k] = reinterpret_cast<const ulonglong2*>(recs)[2 * (size_t)i];
-            rb[k] = reinterpret_cast<const uint4*>(recs)[2 * (size_t)i + 1];      // position, len, max_wait, -
+            const uint4 ra4 = nt_load(&reinterpret_cast<const uint4*>(recs)[2 * (size_t)i]);
+            ra[k] = make_ulonglong2(((uint64_t)ra4.y << 32) | ra4.x, ((uint64_t)ra4.w << 32) | ra4.z);
+            rb[k] = nt_load(&reinterpret_cast<const uint4*>(recs)[2 * (size_t)i + 1]);      // position, len, max_wait, -
         }
     }
 #pragma unroll
