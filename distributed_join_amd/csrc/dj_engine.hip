@@ -629,14 +629,10 @@ static int join_launch(dj_engine* e, Work& w, bool serial_only, uint32_t n, cons
     // Bucketed form of the link and resolve passes (no atomic per event): for batches that are large enough to give
     // every compute unit a tile of the first pass (measured, link + resolve pass in us, chain form -> bucketed: 36.8 ->
     // 39.8 at 131072 events, 45.1 -> 41.9 at 196608, 51.2 -> 48.1 at 262144, 64.6 -> 62.1 at 393216, 135 -> 119 at 2^20;
-    // buckets of 512 to 1024 events on average up to 2^20), small enough for a bucket to fit the second
-    // pass's LDS (2048 keys at most; up to 1280 on average, so that a rank's share of a routed batch of 2^20 events per
-    // rank, which comes a little above or below 2^20, stays in this form), on tables of up to 2^22 slots (the second pass finds the lines
-    // that the first one fetched in the 256 MB Infinity Cache as long as not much more than the table competes for it:
-    // with batches applied in pieces of 2^20 events the bucketed form gained 7 % on a table of 2^21 slots, lost 1 % at
-    // 2^22 and 9 % at 2^23 and 2^25: that was a batch of 2^22 events cut into pieces, which costs the chain form's gain from
-    // large launches; a batch that IS about 2^20 events gains on a table of any size — 2^25 slots, link + resolve: 132 us
-    // chained, 121 us bucketed), and whose previous batch showed no long chains (a hot barrier overflows its bucket, and the batch then falls back to chains).
+    // buckets of 512 to 1024 events on average up to 2^20, up to 1280 so that a rank's share of a routed batch of 2^20
+    // events per rank, which comes a little above or below 2^20, keeps plain buckets), on tables of any size (2^25 slots,
+    // batches of 2^20, link + resolve: 132 us chained, 121 us bucketed), and whose previous batch showed no long chains
+    // (a hot barrier overflows its bucket, and the batch then falls back to chains).
     const uint64_t slots = e->t.mask + 1;
     // Batches beyond 1024 buckets x 1280 events: the buckets get fat (bfat x 2048 keys) and the second pass works through
     // a bucket's slot range in bfat sub-ranges; one launch pair whatever the batch size, up to what the key buffer holds.
